@@ -1,0 +1,49 @@
+// Shared host-side plumbing for libseld_hip.so (error reporting, device state).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "logmel_core.h"
+
+namespace seld {
+
+enum : int {
+  kOk = 0,
+  kErrInvalidArgument = -1,
+  kErrHip = -2,
+  kErrNotInitialised = -3,
+  kErrUnsupported = -4,
+};
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define SELD_HIP_TRY(expr)                                                             \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess)                                                              \
+      return ::seld::fail(::seld::kErrHip, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+struct DeviceState {
+  bool ready = false;
+  int device = -1;
+  int num_cus = 0;
+  // log-mel tables (device memory)
+  float* window = nullptr;
+  float* twiddle = nullptr;
+  int* mel_b0 = nullptr;
+  float* mel_wd = nullptr;
+  float* mel_wu = nullptr;
+  float* mel_fb = nullptr;      // dense [481][64] copy (used by the intensity-vector / debug paths)
+  LogmelTables tables() const { return LogmelTables{window, twiddle, mel_b0, mel_wd, mel_wu}; }
+};
+
+// Returns the state of the CURRENT hip device, or nullptr (and sets the error) if seld_init
+// has not been called for it.
+DeviceState* current_state();
+
+}  // namespace seld

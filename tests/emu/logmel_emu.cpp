@@ -1,0 +1,102 @@
+// TEST TOOL (not shipped, not linked into libseld_hip.so): runs the log-mel kernel's per-lane
+// phase functions (csrc/logmel_core.h) on the CPU, 64 "lanes" in lock step with a plain array
+// standing in for the wavefront's LDS tile.  It lets the CPU test-suite check the kernel's
+// index math (32x30 factorisation, packed-frame un-mixing, sparse mel ownership, reflection at
+// the clip edges) against the oracle without a GPU.  The product never calls this.
+//
+//   g++ -O2 -shared -fPIC -I <csrc> tests/emu/logmel_emu.cpp -o tests/emu/libseld_emu.so
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "logmel_core.h"
+#include "logmel_tables.h"
+
+using namespace seld;
+
+namespace {
+
+struct HostTables {
+  std::vector<float> window, twiddle, fb, wd, wu;
+  std::vector<int> b0;
+  LogmelTables view() const { return LogmelTables{window.data(), twiddle.data(), b0.data(), wd.data(), wu.data()}; }
+};
+
+template <typename T>
+int run(const T* pcm, int64_t N, int64_t C, int64_t L, float* out, int layout, const float* fb_opt) {
+  if (L <= kNfft / 2) return -1;
+  HostTables t;
+  hann_window(t.window);
+  stage_twiddles(t.twiddle);
+  if (fb_opt)
+    t.fb.assign(fb_opt, fb_opt + static_cast<size_t>(kBins) * kMels);
+  else
+    default_mel_filterbank(t.fb);
+  if (build_sparse_mel(t.fb, t.b0, t.wd, t.wu)) return -4;
+  const LogmelTables tab = t.view();
+
+  const long F = 1 + L / kHop;
+  const long groups = (F + kFramesPerGroup - 1) / kFramesPerGroup;
+  long sN, sC, sM, sT;
+  if (layout == 0) { sT = 1; sM = F; sC = kMels * F; sN = C * kMels * F; }
+  else { sM = 1; sC = kMels; sT = C * kMels; sN = F * C * kMels; }
+
+  std::vector<float> lds(kLdsFloatsPerWave, 0.0f);
+  std::vector<LaneConst> k(64);
+  for (int lane = 0; lane < 64; ++lane) load_lane_const(lane, tab, k[lane]);
+  std::vector<float> zr(64 * kN2), zi(64 * kN2), mr(64 * 16), mi(64 * 16);
+  std::vector<LaneAcc> acc(64);
+
+  for (long row = 0; row < N * C; ++row) {
+    const T* rowp = pcm + row * L;
+    const long n = row / C, c = row % C;
+    for (long g = 0; g < groups; ++g) {
+      const long t0 = g * kFramesPerGroup;
+      const bool interior = (t0 >= 1) && (static_cast<long>(kHop) * (t0 + kFramesPerGroup) <= L);
+      for (int it = 0; it < kItersPerGroup; ++it) {
+        const long tf = t0 + it * kFramesPerIter;
+        if (tf >= F) break;
+        for (int lane = 0; lane < 64; ++lane) {
+          const long fa = tf + 2 * (lane >> 5);
+          if (interior) phase_a<T, true>(lane, rowp, L, fa, k[lane], lds.data());
+          else phase_a<T, false>(lane, rowp, L, fa, k[lane], lds.data());
+        }
+        for (int lane = 0; lane < 64; ++lane)
+          phase_b(lane, lds.data(), *reinterpret_cast<float(*)[kN2]>(&zr[lane * kN2]),
+                  *reinterpret_cast<float(*)[kN2]>(&zi[lane * kN2]));
+        for (int lane = 0; lane < 64; ++lane)
+          phase_b_store(lane, lds.data(), *reinterpret_cast<float(*)[kN2]>(&zr[lane * kN2]),
+                        *reinterpret_cast<float(*)[kN2]>(&zi[lane * kN2]));
+        for (int lane = 0; lane < 64; ++lane)
+          phase_c_load(lane, lds.data(), *reinterpret_cast<float(*)[16]>(&mr[lane * 16]),
+                       *reinterpret_cast<float(*)[16]>(&mi[lane * 16]));
+        for (int lane = 0; lane < 64; ++lane)
+          phase_c_store(lane, lds.data(), *reinterpret_cast<float(*)[kN2]>(&zr[lane * kN2]),
+                        *reinterpret_cast<float(*)[kN2]>(&zi[lane * kN2]),
+                        *reinterpret_cast<float(*)[16]>(&mr[lane * 16]),
+                        *reinterpret_cast<float(*)[16]>(&mi[lane * 16]));
+        for (int lane = 0; lane < 64; ++lane) phase_d_accumulate(lane, lds.data(), tab, k[lane], acc[lane]);
+        for (int lane = 0; lane < 64; ++lane) {
+          float db[kFramesPerIter];
+          phase_d_finish(lane, lds.data(), acc[lane], db);
+          float* outp = out + n * sN + c * sC + lane * sM;
+          for (int s = 0; s < kFramesPerIter; ++s)
+            if (tf + s < F) outp[(tf + s) * sT] = db[s];
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+int emu_logmel_f32(const float* pcm, int64_t N, int64_t C, int64_t L, float* out, int layout, const float* fb) {
+  return run<float>(pcm, N, C, L, out, layout, fb);
+}
+int emu_logmel_i16(const int16_t* pcm, int64_t N, int64_t C, int64_t L, float* out, int layout, const float* fb) {
+  return run<int16_t>(pcm, N, C, L, out, layout, fb);
+}
+}
