@@ -36,6 +36,10 @@ const char* seld_last_error(void);
  * torchaudio.transforms.MelScale used at dataset.py:38-43. */
 int seld_set_mel_filterbank(const float* fb_host);
 
+/* Override the default (double-precision-rounded) periodic Hann window with a host table w[960],
+ * e.g. torch.hann_window(960) as torchaudio.transforms.Spectrogram builds it in fp32. */
+int seld_set_window(const float* window_host);
+
 /* Host copies of the default tables -- no GPU needed (used by CPU tests). Any pointer may be NULL. */
 int seld_default_tables(float* window960, float* fb481x64, int* mel_b0_64, float* mel_wd_24x64,
                         float* mel_wu_24x64);
@@ -53,6 +57,38 @@ int64_t seld_num_frames(int64_t L);
  * Requires L > 480 (reflect padding), like torch.stft. */
 int seld_logmel_f32(const float* pcm, int64_t N, int64_t C, int64_t L, float* out, int layout, void* stream);
 int seld_logmel_i16(const int16_t* pcm, int64_t N, int64_t C, int64_t L, float* out, int layout, void* stream);
+
+/* ---- labels: dataset.py:60-119 metadata_to_labels + utils.py:77-90 polar_to_grid ---------- */
+/* events: int32 [R][5] = (meta_frame, class, source, azimuth_deg, elevation_deg), the CSV rows after
+ * the reference's int() casts (dataset.py:93-97).  T = int((L/sr*1000)/20) label frames, computed by
+ * the caller with the reference's float64 rule (dataset.py:73).  mask: uint16 [T][I*J], overwritten:
+ * bit c set <=> labels[t, cell, c] == 1.0 from an event row; the background one-hot (class 13 where
+ * no event, dataset.py:114-117) is implied by mask == 0.  Rows with 5*meta_frame >= T are dropped
+ * (empty range in the reference); rows with class outside [0,16) are ignored (the reference raises
+ * IndexError for class >= 14 -- the Python host checks that before upload).  I*J must be even. */
+int seld_labels_rasterise(const int32_t* events, int64_t R, int64_t T, int I, int J, uint16_t* mask, void* stream);
+
+/* mask uint16 [n_cells] -> dense float32 [n_cells][num_classes] exactly as dataset.py:110-117 leaves it. */
+int seld_labels_expand(const uint16_t* mask, int64_t n_cells, int num_classes, float* dense, void* stream);
+
+/* ---- windows: dataset.py:267-317 _create_windows ------------------------------------------ */
+/* dst[b][w][:] = src[starts[b] + w][:] (rows of row_bytes, a multiple of 16) for rows inside
+ * [0, total_rows), zero bytes otherwise: a zero spectrogram pad (dataset.py:293-294) and mask 0 =
+ * background for the labels (dataset.py:298-299).  starts: int64 [B] on the device. */
+int seld_window_gather(const void* src, int64_t total_rows, int64_t row_bytes, const int64_t* starts, int64_t B,
+                       int64_t window, void* dst, void* stream);
+
+/* ---- loss: loss.py:43-54 class_mse_loss (+ its backward) ---------------------------------- */
+/* logits [n_cells][14] (fp32, or bf16 when logits_is_bf16), labels as EITHER the compact mask
+ * (uint16 [n_cells]) OR dense float32 [n_cells][14] (exactly one non-NULL).  Writes
+ * loss_out[0] = mean((softmax(logits) - y)^2) and, if grad != NULL, grad (same dtype/shape as logits)
+ * = grad_scale * p_k * ((p_k - y_k) - sum_c p_c (p_c - y_c)); pass grad_scale = 2*w/(n_cells*14) for
+ * d(w*loss)/dlogits.  workspace: seld_softmax_mse_workspace_bytes() bytes of device scratch.
+ * Deterministic (fixed-order reduction, no float atomics). */
+int64_t seld_softmax_mse_workspace_bytes(void);
+int seld_softmax_mse(const void* logits, int logits_is_bf16, const uint16_t* mask, const float* dense_labels,
+                     int64_t n_cells, int num_classes, float grad_scale, float* loss_out, void* grad,
+                     void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

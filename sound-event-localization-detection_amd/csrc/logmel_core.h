@@ -231,7 +231,9 @@ SELD_HD void phase_d_accumulate(int lane, float* lds, const LogmelTables& t, con
   for (int s = 0; s < kFramesPerIter; ++s) lds[kBsOff + s * 64 + lane] = acc.b[s];
 }
 
-SELD_HD float power_to_db(float p) { return 10.0f * log10f(fmaxf(p, kAmin)); }
+// 10*log10(max(p, 1e-10)); the floor is returned as exactly -100 dB (what the CPU path yields),
+// independent of the last-ulp behaviour of the device log10f.
+SELD_HD float power_to_db(float p) { return p > kAmin ? 10.0f * log10f(p) : -100.0f; }
 
 SELD_HD void phase_d_finish(int lane, const float* lds, const LaneAcc& acc, float (&db)[kFramesPerIter]) {
 #pragma unroll

@@ -1,0 +1,212 @@
+// Fused softmax + MSE class loss (forward value and gradient in one pass) for gfx950.
+//
+// Replaces loss.py:43-54 (class_mse_loss: F.softmax + F.mse_loss over [B,T,648,14]) and its
+// autograd backward: unfused that is >= 6 passes over 9.07 MB-per-window tensors plus a dense
+// 290 MB/step label upload; here the logits are read once, the gradient written once, and the
+// labels come either as the dense float tensor the reference uses or as the compact uint16
+// class mask (labels.hip), expanded in registers.
+//
+//   p = softmax(z),  L = mean_{cells,classes} (p - y)^2
+//   dL/dz_k = (2/(n*M)) * p_k * [ (p_k - y_k) - sum_c p_c (p_c - y_c) ]
+//
+// HBM-bound: 56 B read + 56 B written per cell (fp32 logits, M = 14).  A 256-thread block
+// stages 256 cells (3584 floats) through LDS so that global traffic is full 16-B lanes while
+// each thread owns one cell (stride-14 LDS reads as 7 x ds_read_b64: conflict free).
+#include <hip/hip_bf16.h>
+
+#include "seld_common.h"
+
+namespace seld {
+
+constexpr int kLossBlock = 256;
+
+__device__ __forceinline__ float bf16_bits_to_float(unsigned short b) {
+  return __uint_as_float(static_cast<unsigned>(b) << 16);
+}
+
+__device__ __forceinline__ unsigned short float_to_bf16_bits(float f) {
+  return __bfloat16_as_ushort(__float2bfloat16(f));   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+}
+
+template <int M, bool kBf16, bool kMaskLabels, bool kGrad>
+__global__ __launch_bounds__(kLossBlock) void softmax_mse_kernel(const void* __restrict__ logits_,
+                                                                  const uint16_t* __restrict__ mask,
+                                                                  const float* __restrict__ dense,
+                                                                  long n_cells, float grad_scale,
+                                                                  double* __restrict__ partials,
+                                                                  void* __restrict__ grad_) {
+  __shared__ __attribute__((aligned(16))) float tile[kLossBlock * M];
+  __shared__ double wave_sums[kLossBlock / 64];
+  const int tid = threadIdx.x;
+  double local = 0.0;
+  const long n_tiles = (n_cells + kLossBlock - 1) / kLossBlock;
+
+  for (long tileno = blockIdx.x; tileno < n_tiles; tileno += gridDim.x) {
+    const long cell0 = tileno * kLossBlock;
+    const long cells_here = (n_cells - cell0) < kLossBlock ? (n_cells - cell0) : kLossBlock;
+    const long elems = cells_here * M;
+    // ---- coalesced load of the logits tile into LDS (as fp32)
+    if (kBf16) {
+      const unsigned short* src = static_cast<const unsigned short*>(logits_) + cell0 * M;
+      for (long i = tid * 2; i < elems; i += kLossBlock * 2) {   // elems is even (M = 14)
+        const unsigned v = *reinterpret_cast<const unsigned*>(src + i);
+        tile[i] = bf16_bits_to_float(static_cast<unsigned short>(v & 0xffffu));
+        tile[i + 1] = bf16_bits_to_float(static_cast<unsigned short>(v >> 16));
+      }
+    } else {
+      const float* src = static_cast<const float*>(logits_) + cell0 * M;
+      if ((cell0 * M) % 4 == 0 && elems % 4 == 0) {
+        for (long i = tid * 4; i < elems; i += kLossBlock * 4)
+          *reinterpret_cast<float4*>(tile + i) = *reinterpret_cast<const float4*>(src + i);
+      } else {
+        for (long i = tid; i < elems; i += kLossBlock) tile[i] = src[i];
+      }
+    }
+    __syncthreads();
+
+    // ---- one cell per thread
+    float g[M];
+    if (tid < cells_here) {
+      float z[M], y[M];
+#pragma unroll
+      for (int c = 0; c < M; c += 2) {
+        const float2 v = *reinterpret_cast<const float2*>(tile + tid * M + c);
+        z[c] = v.x;
+        z[c + 1] = v.y;
+      }
+      if (kMaskLabels) {
+        const unsigned m = mask[cell0 + tid];
+#pragma unroll
+        for (int c = 0; c < M; ++c) y[c] = ((m >> c) & 1u) ? 1.0f : 0.0f;
+        if (m == 0u) y[M - 1] = 1.0f;                       // background rule, dataset.py:114-117
+      } else {
+        const float* yp = dense + (cell0 + tid) * M;
+#pragma unroll
+        for (int c = 0; c < M; c += 2) {
+          const float2 v = *reinterpret_cast<const float2*>(yp + c);
+          y[c] = v.x;
+          y[c + 1] = v.y;
+        }
+      }
+      float zmax = z[0];
+#pragma unroll
+      for (int c = 1; c < M; ++c) zmax = fmaxf(zmax, z[c]);
+      float denom = 0.0f;
+#pragma unroll
+      for (int c = 0; c < M; ++c) {
+        z[c] = __expf(z[c] - zmax);
+        denom += z[c];
+      }
+      const float inv = 1.0f / denom;
+      float sq = 0.0f, dot = 0.0f;
+#pragma unroll
+      for (int c = 0; c < M; ++c) {
+        const float p = z[c] * inv;
+        const float d = p - y[c];
+        sq = fmaf(d, d, sq);
+        dot = fmaf(p, d, dot);
+        z[c] = p;
+        y[c] = d;
+      }
+      local += static_cast<double>(sq);
+      if (kGrad) {
+#pragma unroll
+        for (int c = 0; c < M; ++c) g[c] = grad_scale * z[c] * (y[c] - dot);
+      }
+    }
+    if (kGrad) {
+      __syncthreads();   // everyone has read its logits: reuse the tile for the gradient
+      if (tid < cells_here) {
+#pragma unroll
+        for (int c = 0; c < M; c += 2) *reinterpret_cast<float2*>(tile + tid * M + c) = make_float2(g[c], g[c + 1]);
+      }
+      __syncthreads();
+      if (kBf16) {
+        unsigned short* dst = static_cast<unsigned short*>(grad_) + cell0 * M;
+        for (long i = tid * 2; i < elems; i += kLossBlock * 2) {
+          const unsigned lo = float_to_bf16_bits(tile[i]);
+          const unsigned hi = float_to_bf16_bits(tile[i + 1]);
+          *reinterpret_cast<unsigned*>(dst + i) = lo | (hi << 16);
+        }
+      } else {
+        float* dst = static_cast<float*>(grad_) + cell0 * M;
+        if ((cell0 * M) % 4 == 0 && elems % 4 == 0) {
+          for (long i = tid * 4; i < elems; i += kLossBlock * 4)
+            *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(tile + i);
+        } else {
+          for (long i = tid; i < elems; i += kLossBlock) dst[i] = tile[i];
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- deterministic block reduction of the squared-error sum (double)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+  if ((tid & 63) == 0) wave_sums[tid >> 6] = local;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0;
+    for (int w = 0; w < kLossBlock / 64; ++w) s += wave_sums[w];
+    partials[blockIdx.x] = s;
+  }
+}
+
+// Fixed-order final reduction -> mean squared error as float.
+__global__ void loss_finish_kernel(const double* __restrict__ partials, int n, double inv_count, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += partials[i];
+    out[0] = static_cast<float>(s * inv_count);
+  }
+}
+
+template <bool kBf16, bool kMaskLabels, bool kGrad>
+static void launch(unsigned blocks, hipStream_t stream, const void* logits, const uint16_t* mask, const float* dense,
+                   long n_cells, float grad_scale, double* partials, void* grad) {
+  hipLaunchKernelGGL((softmax_mse_kernel<14, kBf16, kMaskLabels, kGrad>), dim3(blocks), dim3(kLossBlock), 0, stream,
+                     logits, mask, dense, n_cells, grad_scale, partials, grad);
+}
+
+}  // namespace seld
+
+extern "C" {
+
+int64_t seld_softmax_mse_workspace_bytes(void) { return 4096 * sizeof(double); }
+
+int seld_softmax_mse(const void* logits, int logits_is_bf16, const uint16_t* mask, const float* dense_labels,
+                     int64_t n_cells, int num_classes, float grad_scale, float* loss_out, void* grad,
+                     void* workspace, void* stream_) {
+  using namespace seld;
+  DeviceState* st = current_state();
+  if (!st) return kErrNotInitialised;
+  if (num_classes != 14) return fail(kErrUnsupported, "seld_softmax_mse: built for 14 classes (config.py:40)");
+  if (n_cells <= 0) return fail(kErrInvalidArgument, "seld_softmax_mse: n_cells must be positive");
+  if (!logits || !loss_out || !workspace) return fail(kErrInvalidArgument, "seld_softmax_mse: null pointer");
+  if ((mask == nullptr) == (dense_labels == nullptr))
+    return fail(kErrInvalidArgument, "seld_softmax_mse: pass exactly one of mask / dense_labels");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  long tiles = (n_cells + kLossBlock - 1) / kLossBlock;
+  long blocks = static_cast<long>(st->num_cus) * 8;
+  if (blocks > tiles) blocks = tiles;
+  if (blocks > 4096) blocks = 4096;
+  double* partials = static_cast<double*>(workspace);
+  const unsigned nb = static_cast<unsigned>(blocks);
+  const bool bf = logits_is_bf16 != 0, mk = mask != nullptr, gr = grad != nullptr;
+  const long n = n_cells;
+#define SELD_DISPATCH(B, K, G) \
+  if (bf == B && mk == K && gr == G) launch<B, K, G>(nb, stream, logits, mask, dense_labels, n, grad_scale, partials, grad)
+  SELD_DISPATCH(false, false, false); SELD_DISPATCH(false, false, true);
+  SELD_DISPATCH(false, true, false);  SELD_DISPATCH(false, true, true);
+  SELD_DISPATCH(true, false, false);  SELD_DISPATCH(true, false, true);
+  SELD_DISPATCH(true, true, false);   SELD_DISPATCH(true, true, true);
+#undef SELD_DISPATCH
+  SELD_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, stream, partials, static_cast<int>(nb),
+                     1.0 / (static_cast<double>(n_cells) * num_classes), loss_out);
+  SELD_HIP_TRY(hipGetLastError());
+  return kOk;
+}
+
+}  // extern "C"

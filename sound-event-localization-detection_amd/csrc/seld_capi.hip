@@ -117,6 +117,15 @@ int seld_set_mel_filterbank(const float* fb_host) {
   return upload_mel(*st, fb);
 }
 
+int seld_set_window(const float* window_host) {
+  using namespace seld;
+  DeviceState* st = current_state();
+  if (!st) return kErrNotInitialised;
+  if (!window_host) return fail(kErrInvalidArgument, "seld_set_window: null table");
+  SELD_HIP_TRY(hipMemcpy(st->window, window_host, kNfft * sizeof(float), hipMemcpyHostToDevice));
+  return kOk;
+}
+
 // Host-side copies of the constant tables (no GPU needed): lets CPU tests check the C++
 // default filterbank / sparse decomposition against the oracle.
 int seld_default_tables(float* window960, float* fb481x64, int* mel_b0_64, float* mel_wd_24x64,

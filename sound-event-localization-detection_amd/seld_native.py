@@ -1,0 +1,263 @@
+"""ctypes binding of ``libseld_hip.so`` (C ABI: ``include/seld_hip.h``).
+
+PyTorch is used for device memory and streams only; every entry point below hands raw
+device pointers (``tensor.data_ptr()``) and the current HIP stream to the hand-written
+gfx950 kernels.  There is NO CPU fallback: if the shared library is missing or a GPU call
+fails, a ``RuntimeError`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from pathlib import Path
+
+import torch
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libseld_hip.so"
+
+N_FFT = 960
+HOP = 480
+N_BINS = 481
+N_MELS = 64
+
+_lock = threading.Lock()
+_lib = None
+_initialised_devices = set()
+
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_ptr = ctypes.c_void_p
+
+
+class SeldNativeError(RuntimeError):
+    pass
+
+
+def _declare(lib):
+    lib.seld_last_error.restype = ctypes.c_char_p
+    lib.seld_last_error.argtypes = []
+    lib.seld_version.restype = _int
+    lib.seld_init.argtypes = [_int]
+    lib.seld_shutdown.argtypes = []
+    lib.seld_set_mel_filterbank.argtypes = [_ptr]
+    lib.seld_set_window.argtypes = [_ptr]
+    lib.seld_default_tables.argtypes = [_ptr] * 5
+    lib.seld_num_frames.restype = _i64
+    lib.seld_num_frames.argtypes = [_i64]
+    for name in ("seld_logmel_f32", "seld_logmel_i16"):
+        getattr(lib, name).argtypes = [_ptr, _i64, _i64, _i64, _ptr, _int, _ptr]
+    lib.seld_labels_rasterise.argtypes = [_ptr, _i64, _i64, _int, _int, _ptr, _ptr]
+    lib.seld_labels_expand.argtypes = [_ptr, _i64, _int, _ptr, _ptr]
+    lib.seld_window_gather.argtypes = [_ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr]
+    lib.seld_softmax_mse_workspace_bytes.restype = _i64
+    lib.seld_softmax_mse_workspace_bytes.argtypes = []
+    lib.seld_softmax_mse.argtypes = [_ptr, _int, _ptr, _ptr, _i64, _int, ctypes.c_float, _ptr, _ptr, _ptr, _ptr]
+    return lib
+
+
+def load_library():
+    """Load (once) and return the ctypes handle.  Fails loudly when the .so is absent."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not LIB_PATH.exists():
+                raise SeldNativeError(
+                    f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    f"or `make -C {_HERE / 'csrc'}`.  There is no CPU fallback.")
+            _lib = _declare(ctypes.CDLL(str(LIB_PATH)))
+        return _lib
+
+
+def check(rc: int, what: str = "libseld_hip"):
+    if rc != 0:
+        msg = load_library().seld_last_error()
+        raise SeldNativeError(f"{what} failed with code {rc}: {msg.decode() if msg else '?'}")
+
+
+def _stream_ptr(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def mel_filterbank() -> torch.Tensor:
+    """fp32 HTK filterbank [481, 64] built with the same torch ops as
+    ``torchaudio.functional.melscale_fbanks(481, 0, 12000, 64, 24000, norm=None, mel_scale='htk')``
+    (the constant inside the MelScale the reference instantiates at dataset.py:38-43)."""
+    import math
+    all_freqs = torch.linspace(0, 24000 // 2, N_BINS)
+    m_max = 2595.0 * math.log10(1.0 + 12000.0 / 700.0)
+    m_pts = torch.linspace(0.0, m_max, N_MELS + 2)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    rising = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    falling = slopes[:, 2:] / f_diff[1:]
+    return torch.clamp(torch.min(rising, falling), min=0.0).contiguous()
+
+
+def ensure_init(device) -> int:
+    """seld_init for ``device`` (idempotent) and upload of the torch-built mel table."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise SeldNativeError(f"the SELD HIP path needs a ROCm device, got {device}")
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    lib = load_library()
+    with _lock:
+        if index in _initialised_devices:
+            return index
+    with torch.cuda.device(index):
+        check(lib.seld_init(index), "seld_init")
+        fb = mel_filterbank()
+        check(lib.seld_set_mel_filterbank(ctypes.c_void_p(fb.data_ptr())), "seld_set_mel_filterbank")
+        win = torch.hann_window(N_FFT, periodic=True, dtype=torch.float32).contiguous()
+        check(lib.seld_set_window(ctypes.c_void_p(win.data_ptr())), "seld_set_window")
+    with _lock:
+        _initialised_devices.add(index)
+    return index
+
+
+def num_frames(num_samples: int) -> int:
+    return 1 + int(num_samples) // HOP
+
+
+def logmel(pcm: torch.Tensor, layout: str = "cft", out: torch.Tensor | None = None) -> torch.Tensor:
+    """Fused log-mel on the GPU.  ``pcm``: [N, C, L] or [C, L], float32 in [-1, 1) or int16.
+
+    layout 'cft' -> [N, C, 64, F] (reference layout, dataset.py:53)
+    layout 'tcf' -> [N, F, C, 64] (time-major; windows are contiguous slices)
+    """
+    squeeze = pcm.dim() == 2
+    if squeeze:
+        pcm = pcm.unsqueeze(0)
+    if pcm.dim() != 3:
+        raise ValueError("pcm must be [N, C, L] or [C, L]")
+    if not pcm.is_cuda:
+        raise SeldNativeError("logmel: pcm must live on the GPU (no CPU fallback in the product path)")
+    if pcm.dtype not in (torch.float32, torch.int16):
+        raise TypeError(f"logmel: pcm dtype must be float32 or int16, got {pcm.dtype}")
+    pcm = pcm.contiguous()
+    n, c, length = pcm.shape
+    index = ensure_init(pcm.device)
+    frames = num_frames(length)
+    code = {"cft": 0, "tcf": 1}[layout]
+    shape = (n, c, N_MELS, frames) if code == 0 else (n, frames, c, N_MELS)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=pcm.device)
+    elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError(f"logmel: out must be contiguous float32 {shape}")
+    lib = load_library()
+    fn = lib.seld_logmel_f32 if pcm.dtype == torch.float32 else lib.seld_logmel_i16
+    with torch.cuda.device(index):
+        check(fn(ctypes.c_void_p(pcm.data_ptr()), n, c, length, ctypes.c_void_p(out.data_ptr()), code,
+                 _stream_ptr(pcm.device)), "seld_logmel")
+    return out[0] if squeeze else out
+
+
+# --------------------------------------------------------------------------- labels / windows
+
+GRID_I, GRID_J = 18, 36
+NUM_CLASSES = 14
+
+
+def _p(t: torch.Tensor | None):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def rasterise_labels(events: torch.Tensor, total_frames: int, I: int = GRID_I, J: int = GRID_J,
+                     device=None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """dataset.py:60-119 on the GPU.  ``events``: int [R, 5] rows (meta_frame, class, source, az, el).
+    Returns the compact class mask, uint16 [total_frames, I*J] (bit c <=> class c active)."""
+    events = torch.as_tensor(events)
+    if events.numel() and (events.dim() != 2 or events.shape[1] < 5):
+        raise ValueError("events must be [R, >=5]")
+    if events.numel():
+        cls = events[:, 1]
+        if int(cls.max()) >= NUM_CLASSES or int(cls.min()) < 0:
+            raise IndexError("metadata class index out of range for 14 classes (dataset.py:110)")
+    device = torch.device(device) if device is not None else (events.device if events.is_cuda else None)
+    if device is None:
+        raise SeldNativeError("rasterise_labels: pass device= (no CPU fallback)")
+    index = ensure_init(device)
+    ev = events[:, :5].to(device=device, dtype=torch.int32).contiguous() if events.numel() else \
+        torch.zeros((0, 5), dtype=torch.int32, device=device)
+    if out is None:
+        out = torch.empty((total_frames, I * J), dtype=torch.uint16, device=device)
+    with torch.cuda.device(index):
+        check(load_library().seld_labels_rasterise(_p(ev), ev.shape[0], total_frames, I, J, _p(out),
+                                                   _stream_ptr(device)), "seld_labels_rasterise")
+    return out
+
+
+def expand_labels(mask: torch.Tensor, num_classes: int = NUM_CLASSES) -> torch.Tensor:
+    """uint16 [..., G] -> float32 [..., G, num_classes] (dataset.py:110-117 semantics)."""
+    if not mask.is_cuda or mask.dtype != torch.uint16:
+        raise SeldNativeError("expand_labels: mask must be a uint16 GPU tensor")
+    mask = mask.contiguous()
+    index = ensure_init(mask.device)
+    out = torch.empty(tuple(mask.shape) + (num_classes,), dtype=torch.float32, device=mask.device)
+    with torch.cuda.device(index):
+        check(load_library().seld_labels_expand(_p(mask), mask.numel(), num_classes, _p(out),
+                                                _stream_ptr(mask.device)), "seld_labels_expand")
+    return out
+
+
+def gather_windows(src: torch.Tensor, starts: torch.Tensor, window: int) -> torch.Tensor:
+    """dataset.py:267-317: src [T, ...] (time-major rows) -> [B, window, ...], zero padded past T."""
+    if not src.is_cuda:
+        raise SeldNativeError("gather_windows: src must be a GPU tensor")
+    src = src.contiguous()
+    row_bytes = src[0].numel() * src.element_size() if src.shape[0] else 0
+    index = ensure_init(src.device)
+    starts = starts.to(device=src.device, dtype=torch.int64).contiguous()
+    out = torch.empty((starts.numel(), window) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    if row_bytes == 0:
+        raise ValueError("gather_windows: empty source")
+    with torch.cuda.device(index):
+        check(load_library().seld_window_gather(_p(src), src.shape[0], row_bytes, _p(starts), starts.numel(),
+                                                window, _p(out), _stream_ptr(src.device)), "seld_window_gather")
+    return out
+
+
+# --------------------------------------------------------------------------- fused loss
+
+_workspaces = {}
+
+
+def _workspace(device) -> torch.Tensor:
+    key = (device.type, device.index)
+    ws = _workspaces.get(key)
+    if ws is None:
+        ws = torch.empty(load_library().seld_softmax_mse_workspace_bytes(), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def softmax_mse(logits: torch.Tensor, labels: torch.Tensor, grad_scale: float | None = None):
+    """loss.py:43-54 fused.  ``labels``: uint16 mask [...cells] or dense float32 [...cells, 14].
+    Returns (loss scalar tensor, grad or None); grad has the dtype/shape of ``logits``."""
+    if not logits.is_cuda:
+        raise SeldNativeError("softmax_mse: logits must be a GPU tensor")
+    if logits.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("softmax_mse: logits must be float32 or bfloat16")
+    logits = logits.contiguous()
+    m = logits.shape[-1]
+    n_cells = logits.numel() // m
+    index = ensure_init(logits.device)
+    labels = labels.contiguous()
+    if labels.dtype == torch.uint16:
+        if labels.numel() != n_cells:
+            raise ValueError("softmax_mse: mask shape does not match logits")
+        mask_p, dense_p = _p(labels), None
+    else:
+        if labels.dtype != torch.float32 or labels.numel() != logits.numel():
+            raise ValueError("softmax_mse: dense labels must be float32 with the logits' shape")
+        mask_p, dense_p = None, _p(labels)
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    grad = torch.empty_like(logits) if grad_scale is not None else None
+    with torch.cuda.device(index):
+        check(load_library().seld_softmax_mse(_p(logits), int(logits.dtype == torch.bfloat16), mask_p, dense_p,
+                                              n_cells, m, float(grad_scale or 0.0), _p(loss), _p(grad),
+                                              _p(_workspace(logits.device)), _stream_ptr(logits.device)),
+              "seld_softmax_mse")
+    return loss[0], grad
