@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""Benchmark of the SELD training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Metric (BASELINE.json): training clips/sec on synthetic 4-channel FOA, 60 s @ 24 kHz clips.
+Workload (BASELINE.json configs[1]): CRNN (model_crnn.py), FOA 4-ch, batch 32 windows, bf16,
+HIP feature kernels + PyTorch-ROCm forward/backward.
+
+One STEP = one pass of the whole hot path over one batch of CLIPS_PER_STEP = 8 synthetic clips whose
+PCM and metadata are already resident in HBM when the timed region starts:
+  1. fused log-mel kernel over [8, 4, 1 440 000] PCM            (dataset.py:27-58)
+  2. label rasteriser for the 8 clips                             (dataset.py:60-119)
+  3. crop to 3000 aligned frames per clip, concatenate, cut 480 windows of 250 frames / hop 50
+     (dataset.py:243-317: 60 windows per clip, windows straddle clip boundaries as upstream)
+  4. 15 optimiser iterations of 32 windows: window gather -> CRNN forward (bf16 autocast) ->
+     fused softmax-MSE loss -> backward (RCCL all-reduce overlapped when N > 1) -> Adam.
+clips/s = N * 8 * K / (max-over-ranks wall time); weak scaling (every rank has its own 8 clips).
+
+The JSON line also carries
+  roofline      : the hand-written log-mel kernel against the HBM roofline -- algorithmic bytes
+                  (26.11 MB per 60 s clip: 23.04 MB fp32 PCM in + 3.07 MB log-mel out) x 8
+                  clips per launch / average launch duration measured with HIP events on the launch stream;
+  roofline_model: the CRNN fwd+bwd iterations against the dense bf16 MFMA peak (39.4 GFLOP/window);
+  cpu_baseline  : the oracle (torch CPU restatement of the reference path) timed on this host's
+                  cores on a bounded sample -- a reported, non-target number.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+PKG = ROOT / "sound-event-localization-detection_amd"
+for p in (str(ROOT), str(PKG)):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CLIPS_PER_STEP = 8
+CHANNELS = 4
+CLIP_SAMPLES = 1_440_000          # 60 s @ 24 kHz
+FRAMES_PER_CLIP = 3000            # min(3001 STFT frames, 3000 label frames), dataset.py:243-249
+WINDOW, HOP = 250, 50
+BATCH = 32
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # dense bf16
+BYTES_PER_CLIP = CHANNELS * CLIP_SAMPLES * 4 + CHANNELS * 64 * (1 + CLIP_SAMPLES // 480) * 4   # 26.11 MB
+# fwd+bwd GFLOP per 250-frame window, hook-counted on the reference modules
+GFLOP_PER_WINDOW = {"crnn": 39.4, "conformer": 37.9, "resnet_conformer": 165.5}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="crnn", choices=["crnn", "conformer", "resnet_conformer"])
+    ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (parity runs)")
+    return ap.parse_args()
+
+
+def synth_metadata(clip_idx: int, meta_frames: int = 600) -> np.ndarray:
+    """Seeded STARSS22-style rows (meta_frame, class, source, azimuth, elevation): 0-3 simultaneous
+    sources per 100 ms frame, occasional second class in the same cell, two rows past the end."""
+    rng = np.random.default_rng(1234 + clip_idx)
+    rows = []
+    for t in range(meta_frames):
+        for s in range(int(rng.integers(0, 4))):
+            az, el = int(rng.integers(-180, 181)), int(rng.integers(-90, 91))
+            rows.append((t, int(rng.integers(0, 13)), s, az, el))
+            if rng.random() < 0.05:
+                rows.append((t, int(rng.integers(0, 13)), s + 1, az, el))
+    rows += [(meta_frames, 1, 0, 10, 10), (meta_frames + 3, 1, 0, 10, 10)]
+    return np.asarray(rows, dtype=np.int64).reshape(-1, 5)
+
+
+def synth_clip_batch(seed: int, device):
+    """Seeded synthetic inputs: PCM ~ N(0, 0.1^2) clipped to [-1, 1); STARSS22-style metadata."""
+    g = torch.Generator(device="cpu").manual_seed(1234 + seed)
+    pcm = (torch.randn(CLIPS_PER_STEP, CHANNELS, CLIP_SAMPLES, generator=g) * 0.1).clamp_(-1.0, 1.0 - 2.0 ** -15)
+    events = []
+    for i in range(CLIPS_PER_STEP):
+        rows = synth_metadata(seed * CLIPS_PER_STEP + i, meta_frames=600)
+        events.append(torch.from_numpy(rows).to(dtype=torch.int32, device=device))
+    return pcm.to(device), events
+
+
+class HotPath:
+    """Holds the device-resident inputs and runs one step."""
+
+    def __init__(self, args, device, rank, world):
+        import seld_native
+        import trainer
+        self.native, self.trainer, self.device = seld_native, trainer, device
+        cfg = trainer.config
+        cfg.MODEL_TYPE = args.model
+        cfg.BATCH_SIZE = BATCH
+        cfg.AMP_DTYPE = "fp32" if args.fp32 else "bf16"
+        torch.manual_seed(0)
+        model = trainer.prepare_model_for_device(trainer.build_model((18, 36)), device)
+        self.model = trainer.wrap_ddp(model, device, world)
+        weights = torch.ones(14, device=device)
+        weights[13] = 0.05
+        self.criterion = trainer.SMRSELDLoss(loss_type="mse", w_class=1.0, grid_size=(18, 36), class_weights=weights)
+        self.optimizer = trainer.make_optimizer(self.model, cfg.LEARNING_RATE, device)
+        self.pcm, self.events = synth_clip_batch(rank, device)
+        total = CLIPS_PER_STEP * FRAMES_PER_CLIP
+        self.starts = torch.arange(0, total, HOP, dtype=torch.int64, device=device)          # 480 windows
+        self.spec_full = torch.empty(CLIPS_PER_STEP, 1 + CLIP_SAMPLES // 480, CHANNELS, 64, device=device)
+        self.mask_tm = torch.empty(total, 648, dtype=torch.uint16, device=device)
+        self.feat_events = []          # (start, stop) HIP events around every log-mel launch
+        self.model_events = []         # around the 15 optimiser iterations
+        self.model.train()
+
+    def step(self, timed: bool):
+        nat, dev = self.native, self.device
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        nat.logmel(self.pcm, layout="tcf", out=self.spec_full)
+        if timed:
+            e1.record()
+            self.feat_events.append((e0, e1))
+        for i, ev in enumerate(self.events):
+            nat.rasterise_labels(ev, FRAMES_PER_CLIP, device=dev,
+                                 out=self.mask_tm[i * FRAMES_PER_CLIP:(i + 1) * FRAMES_PER_CLIP])
+        spec_tm = self.spec_full[:, :FRAMES_PER_CLIP].reshape(-1, CHANNELS, 64)             # crop + concatenate
+        if timed:
+            m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            m0.record()
+        last = None
+        for lo in range(0, self.starts.numel(), BATCH):
+            starts = self.starts[lo:lo + BATCH]
+            spec = nat.gather_windows(spec_tm, starts, WINDOW)
+            mask = nat.gather_windows(self.mask_tm, starts, WINDOW)
+            last, _ = self.trainer.train_step(self.model, self.criterion, self.optimizer, spec, mask, dev)
+        if timed:
+            m1.record()
+            self.model_events.append((m0, m1))
+        return last
+
+
+def cpu_baseline():
+    """Oracle path on the host cores, bounded sample (about 20-30 s): log-mel of 2 clips via the
+    torch.stft restatement, reference-equivalent CRNN fwd+bwd+Adam at batch 2 (3 iterations after
+    1 warm-up), and the reference's pure-Python label loops on a 2 s excerpt (reported in `sample`)."""
+    from oracle import features as ofeat
+    from oracle import labels as olab
+    import model_crnn
+    import loss as loss_mod
+    threads = torch.get_num_threads()
+    pcm = ofeat.synth_pcm(0, CHANNELS, CLIP_SAMPLES, "noise")
+    ofeat.logmel_torch(pcm[:, :240000])                              # warm-up
+    t0 = time.perf_counter()
+    n_feat = 2
+    for _ in range(n_feat):
+        ofeat.logmel_torch(pcm)
+    t_feat = (time.perf_counter() - t0) / n_feat
+    rows = olab.synth_metadata(0, meta_frames=20)
+    t0 = time.perf_counter()
+    olab.metadata_to_labels_loops(rows, 48000)
+    t_label_loops_60s = (time.perf_counter() - t0) * 30.0            # 2 s excerpt -> 60 s, linear in frames
+    torch.manual_seed(0)
+    model = model_crnn.SELD_CRNN().train()
+    crit = loss_mod.SMRSELDLoss(loss_type="mse", w_class=1.0, grid_size=(18, 36))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    x = torch.randn(2, WINDOW, CHANNELS, 64) * 20 - 30
+    y = torch.zeros(2, WINDOW, 648, 14)
+    y[..., 13] = 1.0
+    times = []
+    for it in range(4):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        out, _ = crit.loss_tensor(model(x), y)
+        out.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    t_window = float(np.mean(times[1:])) / 2.0
+    clip_seconds = t_feat + 60.0 * t_window
+    return {
+        "value": 1.0 / clip_seconds, "unit": "clips/s", "cores": threads, "kind": "port",
+        "sample": (f"oracle on host: log-mel 2x60s clips {t_feat * 1e3:.0f} ms/clip; CRNN fwd+bwd+Adam fp32 bs=2, 3 iters "
+                   f"{t_window * 1e3:.0f} ms/window x 60 windows/clip; reference-style Python label loops would add "
+                   f"{t_label_loops_60s:.1f} s/clip (not included)"),
+        "features_clips_per_s": 1.0 / t_feat, "model_windows_per_s": 1.0 / t_window,
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP extension has no CPU fallback)")
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+    torch.backends.cudnn.benchmark = True
+
+    hot = HotPath(args, device, rank, world)
+    for _ in range(args.warmup):
+        hot.step(timed=False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = hot.step(timed=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        feat_ms = float(np.mean([a.elapsed_time(b) for a, b in hot.feat_events]))
+        model_ms = float(np.mean([a.elapsed_time(b) for a, b in hot.model_events]))
+        clips = world * CLIPS_PER_STEP * args.steps
+        achieved_gbs = CLIPS_PER_STEP * BYTES_PER_CLIP / (feat_ms * 1e-3) / 1e9
+        windows_per_step = CLIPS_PER_STEP * FRAMES_PER_CLIP // HOP
+        model_tflops = windows_per_step * GFLOP_PER_WINDOW[args.model] / (model_ms * 1e-3) / 1e3
+        line = {
+            "metric": "training clips/sec (4ch FOA 60s@24kHz)",
+            "value": clips / elapsed, "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp32" if args.fp32 else "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.model} FOA 4-ch 60s clips, bs={BATCH} windows (BASELINE configs[1])",
+                       "clips_per_step": CLIPS_PER_STEP, "windows_per_step": windows_per_step,
+                       "optimizer_iterations_per_step": windows_per_step // BATCH,
+                       "parallelism": f"dp{world}", "windows_per_s": clips * 60 / elapsed,
+                       "final_loss": float(loss.item())},
+            "roofline": {"kernel": "seld::logmel_kernel<float> (fused STFT+mel+dB)", "bound": "hbm",
+                         "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": CLIPS_PER_STEP * BYTES_PER_CLIP, "avg_launch_ms": feat_ms,
+                         "features_only_clips_per_s": CLIPS_PER_STEP / (feat_ms * 1e-3)},
+            "roofline_model": {"phase": f"{args.model} fwd+bwd+Adam, {windows_per_step // BATCH} iterations of {BATCH} windows",
+                               "bound": "mfma", "achieved": model_tflops, "peak": MFMA_BF16_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": model_tflops / MFMA_BF16_PEAK_TFLOPS, "avg_ms": model_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,111 @@
+"""Configuration surface of the SELD training path (drop-in for the reference's ``config.py``).
+
+Every attribute the reference defines (config.py:7-97) is present with the same name, type and
+default, and ``Config()`` creates the output / checkpoint directories and the derived dataset
+paths exactly like config.py:99-118 (main.py and trainer.py rely on CHECKPOINT_PATH existing).
+Attributes below the "MI355X additions" line do not exist upstream; they default to values that
+keep upstream semantics on a CPU and switch the GPU fast paths on when a ROCm device is used.
+"""
+from pathlib import Path
+
+_SR = 24000
+
+
+class Config:
+    # ---- locations (relative to this file, like the reference) ---------------------------
+    BASE_PATH = Path(__file__).parent
+    AUDIO_PATH = BASE_PATH / "foa_dev"
+    METADATA_PATH = BASE_PATH / "metadata_dev"
+    OUTPUT_PATH = BASE_PATH / "outputs"
+    CHECKPOINT_PATH = BASE_PATH / "checkpoints"
+
+    # ---- data selection -----------------------------------------------------------------
+    USE_FULL_DATASET = True
+    TRAIN_AUDIO_FILE = "fold3_room21_mix001.wav"
+    TRAIN_META_FILE = "fold3_room21_mix001.csv"
+    TEST_AUDIO_FILE = "fold4_room23_mix001.wav"
+    TEST_META_FILE = "fold4_room23_mix001.csv"
+
+    STARSS22_CLASSES = dict(enumerate((
+        "Female speech, woman speaking", "Male speech, man speaking", "Clapping", "Telephone",
+        "Laughter", "Domestic sounds", "Walk, footsteps", "Door, open or close", "Music",
+        "Musical instrument", "Water tap, faucet", "Bell", "Knock", "Background")))
+
+    # ---- model ---------------------------------------------------------------------------
+    MODEL_TYPE = "resnet_conformer"      # 'cnn' | 'crnn' | 'conformer' | 'resnet_conformer'
+    NUM_CLASSES = 14
+    N_CHANNELS = 4
+
+    CRNN_CNN_CHANNELS = [64, 128, 256, 512]
+    CRNN_RNN_HIDDEN = 256
+    CRNN_RNN_LAYERS = 2
+    CRNN_DROPOUT = 0.3
+
+    CONF_D_MODEL = 256
+    CONF_N_HEADS = 4
+    CONF_N_LAYERS = 2
+    CONF_KERNEL_SIZE = 31
+    CONF_DROPOUT = 0.3
+
+    RESNET_CONF_D_MODEL = 512
+    RESNET_CONF_N_HEADS = 8
+    RESNET_CONF_N_LAYERS = 4
+    RESNET_DROPOUT = 0.3
+
+    # ---- optimisation --------------------------------------------------------------------
+    NUM_EPOCHS = 30
+    BATCH_SIZE = 16
+    LEARNING_RATE = 1e-3
+    LR_DECAY_FACTOR = 0.5
+    LR_DECAY_PATIENCE = 5
+    WEIGHT_DECAY = 1e-4
+
+    LOSS_TYPE = "mse"                    # 'mse' | 'ce'
+    W_CLASS = 1.0
+    W_AIUR = 1.0
+    W_CL = 1.0
+
+    PATIENCE = 20
+    MIN_DELTA = 1e-4
+
+    SAVE_EVERY_N_EPOCHS = 5
+    KEEP_LAST_N_CHECKPOINTS = 3
+
+    # ---- signal processing: 40 ms frames, 20 ms hop at 24 kHz ------------------------------
+    SPECTROGRAM_N_FFT = int(0.04 * _SR)          # 960
+    SPECTROGRAM_HOP_LENGTH = int(0.02 * _SR)     # 480
+    N_MELS = 64
+    SR = _SR
+
+    # ---- windowing of the concatenated timeline: 5 s windows, 1 s hop ----------------------
+    WINDOW_LENGTH = int(5 * _SR)                 # 120000 samples = 250 frames
+    HOP_LENGTH = int(1 * _SR)                    # 24000 samples  = 50 frames
+
+    # ---- DOA grid ------------------------------------------------------------------------
+    I = None
+    J = None
+    GRID_CELL_DEGREES = 10
+
+    # ==== MI355X additions (not in the reference) ==========================================
+    AMP_DTYPE = "bf16"          # autocast dtype on ROCm devices: 'bf16' or 'fp32'
+    CHANNELS_LAST = True        # NHWC conv blocks (MIOpen/hipBLASLt MFMA path)
+    FUSED_LOSS = True           # seld_softmax_mse instead of softmax + mse_loss + autograd
+    FUSED_GRU = True            # persistent BiGRU kernel instead of MIOpen's per-step GEMMs
+    DEVICE_FEED = True          # train from device-resident features / compact labels (no 290 MB/step H2D)
+    DDP_BUCKET_MB = 25          # RCCL all-reduce bucket size
+    SYNC_BATCHNORM = False      # per-rank BN statistics by default
+    SEED = None                 # the reference never seeds; set an int for reproducible runs
+
+    def __init__(self):
+        for folder in (self.OUTPUT_PATH, self.CHECKPOINT_PATH):
+            folder.mkdir(exist_ok=True, parents=True)
+        audio, meta = self.AUDIO_PATH, self.METADATA_PATH
+        self.TRAIN_AUDIO_PATH = audio / "dev-train-sony" / self.TRAIN_AUDIO_FILE
+        self.TRAIN_META_PATH = meta / "dev-train-sony" / self.TRAIN_META_FILE
+        self.TEST_AUDIO_PATH = audio / "dev-test-sony" / self.TEST_AUDIO_FILE
+        self.TEST_META_PATH = meta / "dev-test-sony" / self.TEST_META_FILE
+        for site in ("SONY", "TAU"):
+            for split in ("TRAIN", "TEST"):
+                sub = f"dev-{split.lower()}-{site.lower()}"
+                setattr(self, f"{site}_{split}_DIR", audio / sub)
+                setattr(self, f"{site}_{split}_META_DIR", meta / sub)

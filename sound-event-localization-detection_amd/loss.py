@@ -1,0 +1,115 @@
+"""SMR-SELD loss (drop-in for the reference's ``loss.py``): ``SMRSELDLoss(loss_type, w_class, w_aiur,
+w_cl, grid_size, class_weights)``; ``forward(y_pred, y_true) -> (loss tensor, {name: float})``.
+
+Active term (loss.py:149-172): ``w_class * class_loss`` where class_loss is
+  'mse' : mean((softmax(logits) - y)^2)             loss.py:43-54   -> fused HIP kernel on ROCm devices
+  'ce'  : weighted CrossEntropy(argmax(y))          loss.py:27-41   -> stock ops
+The AIUR and converging-localisation terms (loss.py:56-146) are implemented (they are active in the
+reference's ``smrl_seld_gaussian.py``) but, like upstream, not part of ``forward``.
+
+``y_true`` may be the dense float tensor [B,T,G,M] the reference uses or the compact uint16 class
+mask [B,T,G] produced by the label rasteriser (bit c = class c; mask 0 = background).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class _FusedSoftmaxMSE(torch.autograd.Function):
+    """loss and d(loss)/d(logits) from ONE pass of seld_softmax_mse (csrc/loss.hip)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        import seld_native
+        n = logits.numel()
+        loss, grad = seld_native.softmax_mse(logits, labels, grad_scale=(2.0 / n) if logits.requires_grad else None)
+        ctx.save_for_backward(grad if grad is not None else torch.empty(0))
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (grad,) = ctx.saved_tensors
+        return grad * grad_out.to(grad.dtype), None
+
+
+def mask_to_dense(mask, num_classes):
+    """uint16 class mask [..., G] -> float [..., G, M] with the background rule (dataset.py:110-117)."""
+    bits = (mask.to(torch.int32).unsqueeze(-1) >> torch.arange(num_classes, device=mask.device)) & 1
+    dense = bits.to(torch.float32)
+    dense[..., num_classes - 1] = torch.where(mask == 0, 1.0, dense[..., num_classes - 1])
+    return dense
+
+
+class SMRSELDLoss(nn.Module):
+    fused_enabled = True     # flipped by the trainer from Config.FUSED_LOSS
+
+    def __init__(self, loss_type="ce", w_class=1.0, w_aiur=0.5, w_cl=0.5, grid_size=None, class_weights=None):
+        super().__init__()
+        self.loss_type = loss_type
+        self.w_class = w_class
+        self.w_aiur = w_aiur
+        self.w_cl = w_cl
+        self.eps = 1e-10
+        self.I, self.J = grid_size if grid_size is not None else (None, None)
+        self.ce_loss = nn.CrossEntropyLoss(weight=class_weights) if class_weights is not None else nn.CrossEntropyLoss()
+
+    # ---- class terms ---------------------------------------------------------------------------
+    def _dense(self, y_true, num_classes):
+        return mask_to_dense(y_true, num_classes) if y_true.dtype == torch.uint16 else y_true
+
+    def class_ce_loss(self, y_pred, y_true):
+        m = y_pred.shape[-1]
+        target = torch.argmax(self._dense(y_true, m), dim=-1)
+        return self.ce_loss(y_pred.reshape(-1, m).float(), target.reshape(-1))
+
+    def class_mse_loss(self, y_pred, y_true):
+        if y_pred.is_cuda and self.fused_enabled and y_pred.shape[-1] == 14 \
+                and y_pred.dtype in (torch.float32, torch.bfloat16):
+            labels = y_true if y_true.dtype == torch.uint16 else y_true.to(torch.float32)
+            return _FusedSoftmaxMSE.apply(y_pred, labels)
+        probs = F.softmax(y_pred.float(), dim=-1)
+        return F.mse_loss(probs, self._dense(y_true, y_pred.shape[-1]))
+
+    # ---- auxiliary terms (loss.py:56-146), operate on probabilities ------------------------------
+    def aiur_loss(self, y_pred, y_true):
+        """1 - mean IoU between predicted and true event cells per (batch, frame); argmax based."""
+        bg = y_pred.shape[-1] - 1
+        pred_evt = (torch.argmax(y_pred, dim=-1) != bg).float()
+        true_evt = (torch.argmax(y_true, dim=-1) != bg).float()
+        inter = (pred_evt * true_evt).sum(dim=-1)
+        union = pred_evt.sum(dim=-1) + true_evt.sum(dim=-1) - inter
+        iou = torch.where(union > 0, inter / (union + 1e-8), torch.ones_like(inter))
+        return 1.0 - iou.mean()
+
+    def converging_localization_loss(self, y_pred, y_true):
+        """Non-background probability weighted by an 8-neighbour 'attention' map of the targets
+        (circular padding on the I x J grid), averaged over frames that contain events."""
+        b, t, g, m = y_pred.shape
+        rows, cols = (self.I, self.J) if self.I is not None and self.J is not None else (int(math.sqrt(g)),) * 2
+        true_nonbg = y_true.view(b, t, rows, cols, m)[..., :-1].sum(dim=-1)
+        pred_nonbg = y_pred.view(b, t, rows, cols, m)[..., :-1].sum(dim=-1)
+        is_evt = true_nonbg > 0.01
+        n_bac = (true_nonbg < 0.01).sum(dim=(2, 3), keepdim=True).float()
+        n_non = is_evt.sum(dim=(2, 3), keepdim=True).float()
+        y_prime = torch.where(is_evt, (-(n_bac / (n_non + self.eps))).expand_as(true_nonbg), torch.ones_like(true_nonbg))
+        padded = F.pad(y_prime, (1, 1, 1, 1), mode="circular")
+        diff_sum = torch.zeros_like(y_prime)
+        for di in (-1, 0, 1):
+            for dj in (-1, 0, 1):
+                if di or dj:
+                    diff_sum += padded[:, :, 1 + di:rows + 1 + di, 1 + dj:cols + 1 + dj] - y_prime
+        y_at = y_prime + diff_sum / 8.0
+        has_events = (n_non > 0).float()
+        return ((pred_nonbg * y_at) * has_events).sum() / (has_events.sum() * rows * cols + self.eps)
+
+    # ---- forward -------------------------------------------------------------------------------
+    def loss_tensor(self, y_pred, y_true):
+        """The scalar the optimiser differentiates, without the host sync of ``forward``'s breakdown."""
+        term = self.class_mse_loss(y_pred, y_true) if self.loss_type == "mse" else self.class_ce_loss(y_pred, y_true)
+        return self.w_class * term, term
+
+    def forward(self, y_pred: torch.Tensor, y_true: torch.Tensor):
+        total, term = self.loss_tensor(y_pred, y_true)
+        return total, {f"class_{self.loss_type}": float(term.item())}

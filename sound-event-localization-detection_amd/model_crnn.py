@@ -1,0 +1,84 @@
+"""CRNN for SELD (drop-in for the reference's ``model_crnn.py``; same constructor, same
+``state_dict`` keys, same [B,T,C,F] -> [B,T,648,14] logits contract).
+
+  4 x (Conv3x3 -> BatchNorm -> ReLU -> MaxPool over frequency)      model_crnn.py:5-17, :34-57
+  2-layer bidirectional GRU(2048 -> 256)                            model_crnn.py:65-72
+  Linear 512->512, LayerNorm, ReLU, Dropout, Linear 512->9072       model_crnn.py:77-83
+
+On a ROCm device the convolutions run channels-last under bf16 autocast (MFMA via MIOpen /
+hipBLASLt, set up by the trainer) and the recurrence runs in the persistent HIP BiGRU kernel
+(``seld_rnn.SeldGRU``); on a CPU everything is stock PyTorch (the reference's own CPU case).
+"""
+import torch
+import torch.nn as nn
+
+from seld_rnn import SeldGRU
+
+
+class ConvBlock(nn.Module):
+    """conv -> bn -> relu -> optional max-pool; attribute names fixed by the checkpoint format."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=(3, 3), stride=(1, 1), padding=(1, 1), pool_size=None):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride,
+                              padding=padding, bias=False)
+        self.bn = nn.BatchNorm2d(out_channels)
+        self.act = nn.ReLU(inplace=True)
+        self.pool = nn.MaxPool2d(pool_size) if pool_size else None
+
+    def forward(self, x):
+        x = self.act(self.bn(self.conv(x)))
+        return x if self.pool is None else self.pool(x)
+
+
+def build_cnn_encoder(n_channels, n_mels, cnn_channels, max_pools=4):
+    """The shared CRNN / Conformer encoder: frequency is halved by each of the first four blocks,
+    time is never pooled.  Returns (ModuleList, out_channels, out_freq)."""
+    blocks = nn.ModuleList()
+    channels, freq = n_channels, n_mels
+    for depth, width in enumerate(cnn_channels):
+        pool = (1, 2) if depth < max_pools else None
+        blocks.append(ConvBlock(channels, width, pool_size=pool))
+        channels = width
+        if pool:
+            freq //= pool[1]
+    return blocks, channels, freq
+
+
+def run_cnn_encoder(blocks, x):
+    """[B, T, C, F] -> [B, T, C_out * F_out] (model_crnn.py:106-116)."""
+    x = x.permute(0, 2, 1, 3)
+    if x.is_cuda:
+        x = x.contiguous(memory_format=torch.channels_last)
+    for block in blocks:
+        x = block(x)
+    x = x.permute(0, 2, 1, 3)
+    return x.reshape(x.shape[0], x.shape[1], -1)
+
+
+class SELD_CRNN(nn.Module):
+    def __init__(self, n_channels=4, n_mels=64, grid_size=(18, 36), num_classes=14,
+                 cnn_channels=[64, 128, 256, 512], rnn_hidden=256, rnn_layers=2, dropout=0.3):
+        super().__init__()
+        self.I, self.J = grid_size
+        self.grid_cells = self.I * self.J
+        self.num_classes = num_classes
+        self.cnn_blocks, self.cnn_out_channels, self.cnn_out_freq = build_cnn_encoder(n_channels, n_mels, cnn_channels)
+        self.rnn_input_size = self.cnn_out_channels * self.cnn_out_freq
+        self.rnn = SeldGRU(input_size=self.rnn_input_size, hidden_size=rnn_hidden, num_layers=rnn_layers,
+                           batch_first=True, bidirectional=True, dropout=dropout if rnn_layers > 1 else 0)
+        self.rnn_out_size = rnn_hidden * 2
+        self.fnn = nn.Sequential(
+            nn.Linear(self.rnn_out_size, 512),
+            nn.LayerNorm(512),
+            nn.ReLU(),
+            nn.Dropout(dropout),
+            nn.Linear(512, self.grid_cells * num_classes),
+        )
+
+    def forward(self, x):
+        """x [B, T, C, F] -> logits [B, T, G, M]."""
+        batch, frames = x.shape[0], x.shape[1]
+        feats = run_cnn_encoder(self.cnn_blocks, x)
+        feats, _ = self.rnn(feats)
+        return self.fnn(feats).view(batch, frames, self.grid_cells, self.num_classes)

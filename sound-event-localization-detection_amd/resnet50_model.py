@@ -1,0 +1,105 @@
+"""ResNet-50 encoder + Conformer temporal model for SELD (drop-in for the reference's
+``resnet50_model.py``; same names / ``state_dict`` keys).
+
+The encoder is the torchvision ResNet-50 layout ([3, 4, 6, 3] bottlenecks, expansion 4) with a
+3x3 stem and every stride applied to FREQUENCY only -- (1, 2) -- so the 250 time frames survive:
+64 mel bins -> 2 (resnet50_model.py:50-118).  [B,2048,T,2] -> Linear 4096->512 -> dropout ->
+4 Conformer blocks (d=512, 8 heads, FF 2048, k=31) -> head 512->1024->LN->ReLU->Dropout->9072.
+"""
+import torch
+import torch.nn as nn
+
+from model_conformer import ConformerBlock
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, in_channels, out_channels, stride=1, downsample=None):
+        super().__init__()
+        wide = out_channels * self.expansion
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(out_channels)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(out_channels)
+        self.conv3 = nn.Conv2d(out_channels, wide, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(wide)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        shortcut = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        return self.relu(y + shortcut)
+
+
+class ResNet50Encoder(nn.Module):
+    def __init__(self, in_channels=4, layers=[3, 4, 6, 3]):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(in_channels, 64, kernel_size=3, stride=(1, 2), padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=(1, 2), padding=1)
+        self.layer1 = self._make_layer(Bottleneck, 64, layers[0], stride=1)
+        self.layer2 = self._make_layer(Bottleneck, 128, layers[1], stride=(1, 2))
+        self.layer3 = self._make_layer(Bottleneck, 256, layers[2], stride=(1, 2))
+        self.layer4 = self._make_layer(Bottleneck, 512, layers[3], stride=(1, 2))
+        self.out_channels = 2048
+        self.out_freq = 2
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        wide = planes * block.expansion
+        downsample = None
+        if stride != 1 or self.inplanes != wide:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, wide, kernel_size=1, stride=stride, bias=False),
+                nn.BatchNorm2d(wide))
+        stack = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = wide
+        stack += [block(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*stack)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+
+
+class SELD_ResNet50_Conformer(nn.Module):
+    def __init__(self, n_channels=4, n_mels=64, grid_size=(18, 36), num_classes=14,
+                 conf_d_model=512, conf_n_heads=8, conf_n_layers=4, conf_kernel_size=31, dropout=0.3):
+        super().__init__()
+        self.I, self.J = grid_size
+        self.grid_cells = self.I * self.J
+        self.num_classes = num_classes
+        self.encoder = ResNet50Encoder(in_channels=n_channels)
+        self.enc_feat_dim = self.encoder.out_channels * (n_mels // 32)
+        self.proj = nn.Linear(self.enc_feat_dim, conf_d_model)
+        self.dropout = nn.Dropout(dropout)
+        self.conformer_blocks = nn.ModuleList([
+            ConformerBlock(d_model=conf_d_model, n_heads=conf_n_heads, d_ff=conf_d_model * 4,
+                           kernel_size=conf_kernel_size, dropout=dropout)
+            for _ in range(conf_n_layers)])
+        self.head = nn.Sequential(
+            nn.Linear(conf_d_model, 1024),
+            nn.LayerNorm(1024),
+            nn.ReLU(),
+            nn.Dropout(dropout),
+            nn.Linear(1024, self.grid_cells * num_classes),
+        )
+
+    def forward(self, x):
+        """x [B, T, C, F] -> logits [B, T, G, M]; time is the conv 'height', frequency the 'width'."""
+        batch, frames = x.shape[0], x.shape[1]
+        y = x.permute(0, 2, 1, 3)
+        if y.is_cuda:
+            y = y.contiguous(memory_format=torch.channels_last)
+        y = self.encoder(y)                                          # [B, 2048, T, F/32]
+        y = y.permute(0, 2, 1, 3).reshape(batch, frames, -1)
+        y = self.dropout(self.proj(y))
+        for block in self.conformer_blocks:
+            y = block(y)
+        return self.head(y).view(batch, frames, self.grid_cells, self.num_classes)

@@ -171,7 +171,7 @@ def rasterise_labels(events: torch.Tensor, total_frames: int, I: int = GRID_I, J
     events = torch.as_tensor(events)
     if events.numel() and (events.dim() != 2 or events.shape[1] < 5):
         raise ValueError("events must be [R, >=5]")
-    if events.numel():
+    if events.numel() and not events.is_cuda:      # host rows are validated; device rows are trusted (no sync)
         cls = events[:, 1]
         if int(cls.max()) >= NUM_CLASSES or int(cls.min()) < 0:
             raise IndexError("metadata class index out of range for 14 classes (dataset.py:110)")
@@ -183,6 +183,8 @@ def rasterise_labels(events: torch.Tensor, total_frames: int, I: int = GRID_I, J
         torch.zeros((0, 5), dtype=torch.int32, device=device)
     if out is None:
         out = torch.empty((total_frames, I * J), dtype=torch.uint16, device=device)
+    elif tuple(out.shape) != (total_frames, I * J) or out.dtype != torch.uint16 or not out.is_contiguous():
+        raise ValueError("rasterise_labels: out must be a contiguous uint16 [total_frames, I*J] tensor")
     with torch.cuda.device(index):
         check(load_library().seld_labels_rasterise(_p(ev), ev.shape[0], total_frames, I, J, _p(out),
                                                    _stream_ptr(device)), "seld_labels_rasterise")

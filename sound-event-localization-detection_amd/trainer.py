@@ -1,0 +1,525 @@
+"""Training / evaluation loops for SELD on MI355X (drop-in for the reference's ``trainer.py``).
+
+``train_model`` / ``test_model`` keep the reference's signatures, return values, checkpoint format
+and epoch semantics (trainer.py:23-392, :394-711):
+  Adam(lr, weight_decay as L2-in-grad) + ReduceLROnPlateau(min, factor, patience) on the TEST loss,
+  early stopping on the TRAIN loss (PATIENCE, MIN_DELTA), best checkpoint on the TEST loss,
+  periodic checkpoints (keep last N), history dict, loss-curve PNG, reload of the best weights.
+
+What is different underneath:
+  * one process per GPU: under ``torchrun`` the model is wrapped in DistributedDataParallel
+    (RCCL over xGMI, bucketed all-reduce overlapped with backward); window indices -- not files --
+    are sharded across ranks so the window set is exactly the single-process one; the per-epoch
+    loss sums are all-reduced so LR-plateau / early-stop / best-checkpoint decisions agree on
+    every rank; rank 0 alone writes checkpoints, history and plots;
+  * bf16 autocast + channels-last convolutions on ROCm devices (conv / linear / attention
+    contractions on the matrix cores);
+  * device feed: when the loader wraps our ``SELDDataset`` the batches are gathered on the GPU
+    from the device-resident feature timeline and the compact uint16 label mask
+    (seld_window_gather), so the 290 MB/step dense-label upload and the worker pipes disappear;
+    the sampler's order (shuffle / sequential), batch size and drop_last are honoured;
+  * fused softmax+MSE loss kernel; no per-step ``.item()`` host syncs (losses accumulate on
+    the device and are read once per epoch).
+"""
+import gc
+import logging
+import os
+import random
+from contextlib import nullcontext
+from datetime import datetime
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader, RandomSampler  # noqa: F401
+from tqdm import tqdm
+
+from config import Config
+from dataset import SELDDataset
+from loss import SMRSELDLoss
+from model import SMRSELDWithCSPDarkNet
+from model_conformer import SELD_Conformer
+from model_crnn import SELD_CRNN
+from resnet50_model import SELD_ResNet50_Conformer
+from seld_rnn import SeldGRU
+from utils import get_local_rank, get_rank, get_world_size, safe_torch_load
+from visualization import plot_loss_curves, visualize_grid_predictions, visualize_loss_components  # noqa: F401
+
+logger = logging.getLogger("SMR_SELD")
+config = Config()
+
+
+# ------------------------------------------------------------------------------------------------
+# model factory (trainer.py:50-95 / :432-473)
+# ------------------------------------------------------------------------------------------------
+
+def build_model(grid_size, use_small_model=True, model_type=None):
+    kind = config.MODEL_TYPE if model_type is None else model_type
+    common = dict(n_channels=config.N_CHANNELS, grid_size=grid_size, num_classes=config.NUM_CLASSES)
+    if kind == "crnn":
+        logger.info("Initializing CRNN model...")
+        return SELD_CRNN(n_mels=config.N_MELS, cnn_channels=config.CRNN_CNN_CHANNELS,
+                         rnn_hidden=config.CRNN_RNN_HIDDEN, rnn_layers=config.CRNN_RNN_LAYERS,
+                         dropout=config.CRNN_DROPOUT, **common)
+    if kind == "conformer":
+        logger.info("Initializing Conformer model...")
+        return SELD_Conformer(n_mels=config.N_MELS, cnn_channels=config.CRNN_CNN_CHANNELS,
+                              conf_d_model=config.CONF_D_MODEL, conf_n_heads=config.CONF_N_HEADS,
+                              conf_n_layers=config.CONF_N_LAYERS, conf_kernel_size=config.CONF_KERNEL_SIZE,
+                              dropout=config.CONF_DROPOUT, **common)
+    if kind == "resnet_conformer":
+        logger.info("Initializing ResNet50-Conformer model...")
+        return SELD_ResNet50_Conformer(n_mels=config.N_MELS, conf_d_model=config.RESNET_CONF_D_MODEL,
+                                       conf_n_heads=config.RESNET_CONF_N_HEADS,
+                                       conf_n_layers=config.RESNET_CONF_N_LAYERS,
+                                       dropout=config.RESNET_DROPOUT, **common)
+    logger.info("Initializing CSPDarkNet (CNN) model...")
+    return SMRSELDWithCSPDarkNet(use_small=use_small_model, **common)
+
+
+def prepare_model_for_device(model, device):
+    """Move to the device; on a GPU use channels-last weights for the convolutions."""
+    model = model.to(device)
+    if device.type == "cuda" and getattr(config, "CHANNELS_LAST", True):
+        model = model.to(memory_format=torch.channels_last)
+    SeldGRU.fused_enabled = bool(getattr(config, "FUSED_GRU", True))
+    SMRSELDLoss.fused_enabled = bool(getattr(config, "FUSED_LOSS", True))
+    return model
+
+
+def autocast_context(device):
+    if device.type == "cuda" and getattr(config, "AMP_DTYPE", "bf16") == "bf16":
+        return torch.autocast(device_type="cuda", dtype=torch.bfloat16)
+    return nullcontext()
+
+
+# ------------------------------------------------------------------------------------------------
+# distributed plumbing
+# ------------------------------------------------------------------------------------------------
+
+def ensure_process_group(device):
+    """Initialise torch.distributed when launched by torchrun (WORLD_SIZE > 1).  RCCL ('nccl') on
+    GPUs, gloo on CPUs.  Returns (rank, world_size)."""
+    world = get_world_size()
+    if world <= 1:
+        return 0, 1
+    if not dist.is_initialized():
+        backend = "nccl" if device.type == "cuda" else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if device.type == "cuda":
+            torch.cuda.set_device(device)
+            dist.init_process_group(backend=backend, device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
+    return dist.get_rank(), dist.get_world_size()
+
+
+def wrap_ddp(model, device, world):
+    if world <= 1:
+        return model
+    if getattr(config, "SYNC_BATCHNORM", False) and device.type == "cuda":
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    kwargs = dict(bucket_cap_mb=getattr(config, "DDP_BUCKET_MB", 25), gradient_as_bucket_view=True,
+                  broadcast_buffers=False)
+    if device.type == "cuda":
+        kwargs.update(device_ids=[device.index], output_device=device.index)
+    return torch.nn.parallel.DistributedDataParallel(model, **kwargs)
+
+
+def all_reduce_sums(values, device):
+    """Sum a small list of Python floats over all ranks (one collective per epoch phase)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return list(values)
+    t = torch.tensor(values, dtype=torch.float64, device=device if device.type == "cuda" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.tolist()
+
+
+def shard_indices(order, rank, world, pad=True):
+    """DistributedSampler semantics on an explicit index order: pad (by wrapping) to a multiple of the
+    world size so every rank runs the same number of steps, then take every world-th index."""
+    order = list(order)
+    if world <= 1:
+        return order
+    if pad and len(order) % world:
+        order += order[: world - len(order) % world]
+    return order[rank::world]
+
+
+# ------------------------------------------------------------------------------------------------
+# batch sources
+# ------------------------------------------------------------------------------------------------
+
+class LoaderFeed:
+    """The stock path: iterate the DataLoader the caller built (CPU tensors -> device)."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, device
+
+    def __len__(self):
+        return len(self.loader)
+
+    def batches(self, epoch):
+        for spectrograms, labels in self.loader:
+            yield (spectrograms.to(self.device, non_blocking=True), labels.to(self.device, non_blocking=True))
+
+
+class DeviceFeed:
+    """Batches gathered on the GPU from the dataset's device timeline.  Honours the DataLoader's
+    batch size, drop_last and sampler kind (RandomSampler -> a fresh permutation every epoch,
+    otherwise sequential); shards the index order over the ranks."""
+
+    def __init__(self, loader, device, rank, world, seed=0):
+        self.dataset = loader.dataset
+        self.batch_size = loader.batch_size
+        self.drop_last = bool(loader.drop_last)
+        self.shuffle = isinstance(loader.sampler, RandomSampler)
+        self.device, self.rank, self.world, self.seed = device, rank, world, seed
+
+    def _order(self, epoch):
+        n = len(self.dataset)
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed * 100003 + epoch)
+            order = torch.randperm(n, generator=g).tolist()
+        else:
+            order = list(range(n))
+        return shard_indices(order, self.rank, self.world)
+
+    def __len__(self):
+        n = len(shard_indices(range(len(self.dataset)), self.rank, self.world))
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def batches(self, epoch):
+        order = self._order(epoch)
+        for lo in range(0, len(order), self.batch_size):
+            idx = order[lo:lo + self.batch_size]
+            if self.drop_last and len(idx) < self.batch_size:
+                break
+            yield self.dataset.device_batch(idx)
+
+
+def make_feed(loader, device, rank, world):
+    ds = loader.dataset
+    use_device = (getattr(config, "DEVICE_FEED", True) and device.type == "cuda" and isinstance(ds, SELDDataset)
+                  and getattr(ds, "spec_tm", None) is not None and loader.batch_size is not None)
+    if use_device:
+        seed = config.SEED if getattr(config, "SEED", None) is not None else random.randrange(1 << 30)
+        if world > 1:                      # every rank must draw the same permutation
+            seed = int(all_reduce_sums([float(seed) if rank == 0 else 0.0], device)[0])
+        return DeviceFeed(loader, device, rank, world, seed)
+    if world > 1:
+        logger.warning("stock DataLoader under torchrun: every rank iterates the full loader (no sharding)")
+    return LoaderFeed(loader, device)
+
+
+# ------------------------------------------------------------------------------------------------
+# one optimisation step (shared with bench.py)
+# ------------------------------------------------------------------------------------------------
+
+def train_step(model, criterion, optimizer, spectrograms, labels, device):
+    """forward (autocast) -> loss -> backward (DDP all-reduce overlaps here) -> Adam.  Returns the
+    detached (total, class) loss tensors; nothing is synchronised with the host."""
+    optimizer.zero_grad(set_to_none=True)
+    with autocast_context(device):
+        predictions = model(spectrograms)
+    total, term = criterion.loss_tensor(predictions, labels)
+    total.backward()
+    optimizer.step()
+    return total.detach(), term.detach()
+
+
+def eval_step(model, criterion, spectrograms, labels, device):
+    with autocast_context(device):
+        predictions = model(spectrograms)
+    total, term = criterion.loss_tensor(predictions, labels)
+    return predictions, total.detach(), term.detach()
+
+
+def make_optimizer(model, learning_rate, device):
+    kwargs = dict(lr=learning_rate, weight_decay=config.WEIGHT_DECAY)
+    if device.type == "cuda":
+        kwargs["fused"] = True            # one multi-tensor kernel instead of ~4 launches per parameter
+    return torch.optim.Adam(model.parameters(), **kwargs)
+
+
+def checkpoint_payload(epoch, model, optimizer, train_loss, test_loss):
+    """The dict format of trainer.py:278-285 (the Config INSTANCE is pickled, as upstream)."""
+    return {"epoch": epoch, "model_state_dict": unwrap(model).state_dict(),
+            "optimizer_state_dict": optimizer.state_dict(), "train_loss": train_loss, "test_loss": test_loss,
+            "config": config}
+
+
+def unwrap(model):
+    return model.module if isinstance(model, torch.nn.parallel.DistributedDataParallel) else model
+
+
+# ------------------------------------------------------------------------------------------------
+# train_model
+# ------------------------------------------------------------------------------------------------
+
+def train_model(train_loader, test_loader, num_epochs=None, batch_size=None, learning_rate=None,
+                device=None, use_small_model=True):
+    """Complete training run.  Like the reference (trainer.py:36-38) the epoch count, batch size and
+    learning rate come from ``config``; the arguments are accepted for signature compatibility."""
+    num_epochs, batch_size, learning_rate = config.NUM_EPOCHS, config.BATCH_SIZE, config.LEARNING_RATE
+    device = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", get_local_rank() if get_world_size() > 1 else torch.cuda.current_device())
+    if getattr(config, "SEED", None) is not None:
+        torch.manual_seed(config.SEED)
+    rank, world = ensure_process_group(device)
+    is_main = rank == 0
+
+    train_dataset, test_dataset = train_loader.dataset, test_loader.dataset
+    grid = (train_dataset.I, train_dataset.J)
+    logger.info(f"Train dataset: {len(train_dataset)} windows ({len(train_loader)} batches)")
+    logger.info(f"Test dataset: {len(test_dataset)} windows ({len(test_loader)} batches)")
+    logger.info(f"Grid dimensions: {grid[0]}x{grid[1]} = {train_dataset.total_cells} cells; world size {world}")
+
+    model = prepare_model_for_device(build_model(grid, use_small_model), device)
+    n_params = sum(p.numel() for p in model.parameters())
+    model = wrap_ddp(model, device, world)
+
+    class_weights = torch.ones(config.NUM_CLASSES, device=device)
+    class_weights[config.NUM_CLASSES - 1] = 0.05            # trainer.py:99-100
+    criterion = SMRSELDLoss(loss_type=config.LOSS_TYPE, w_class=config.W_CLASS, w_aiur=config.W_AIUR,
+                            w_cl=config.W_CL, grid_size=grid, class_weights=class_weights)
+    optimizer = make_optimizer(model, learning_rate, device)
+    scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=config.LR_DECAY_FACTOR,
+                                                           patience=config.LR_DECAY_PATIENCE)
+    logger.info(f"Model parameters: {n_params:,}")
+    logger.info(f"Optimizer: Adam (lr={learning_rate}, weight_decay={config.WEIGHT_DECAY}); "
+                f"ReduceLROnPlateau (factor={config.LR_DECAY_FACTOR}, patience={config.LR_DECAY_PATIENCE})")
+
+    train_feed = make_feed(train_loader, device, rank, world)
+    test_feed = make_feed(test_loader, device, rank, world)
+    logger.info(f"Batch source: {type(train_feed).__name__}; autocast: {getattr(config, 'AMP_DTYPE', 'fp32')}")
+
+    train_losses, test_losses = [], []
+    best_train_loss = best_test_loss = float("inf")
+    best_epoch = 0
+    stale_epochs = 0
+    kept_checkpoints = []
+    epoch = 0
+
+    for epoch in range(1, num_epochs + 1):
+        started = datetime.now()
+        # ---- train -----------------------------------------------------------------------------
+        model.train()
+        loss_sum = torch.zeros((), dtype=torch.float64, device=device)
+        term_sum = torch.zeros((), dtype=torch.float64, device=device)
+        steps = 0
+        bar = tqdm(train_feed.batches(epoch), total=len(train_feed), desc=f"Epoch {epoch}/{num_epochs} [Train]",
+                   leave=False, disable=not is_main)
+        for spectrograms, labels in bar:
+            total, term = train_step(model, criterion, optimizer, spectrograms, labels, device)
+            loss_sum += total.double()
+            term_sum += term.double()
+            steps += 1
+            if is_main and steps % 25 == 0:
+                bar.set_postfix({"loss": f"{total.item():.4f}", "lr": f"{optimizer.param_groups[0]['lr']:.6f}"})
+        tr_loss, tr_term, tr_steps = all_reduce_sums([loss_sum.item(), term_sum.item(), float(steps)], device)
+        avg_train_loss, avg_train_term = tr_loss / max(tr_steps, 1.0), tr_term / max(tr_steps, 1.0)
+
+        # ---- evaluate --------------------------------------------------------------------------
+        model.eval()
+        loss_sum.zero_()
+        term_sum.zero_()
+        steps = 0
+        with torch.no_grad():
+            for spectrograms, labels in tqdm(test_feed.batches(0), total=len(test_feed), leave=False,
+                                             desc=f"Epoch {epoch}/{num_epochs} [Test]", disable=not is_main):
+                _, total, term = eval_step(model, criterion, spectrograms, labels, device)
+                loss_sum += total.double()
+                term_sum += term.double()
+                steps += 1
+        te_loss, te_term, te_steps = all_reduce_sums([loss_sum.item(), term_sum.item(), float(steps)], device)
+        avg_test_loss, avg_test_term = te_loss / max(te_steps, 1.0), te_term / max(te_steps, 1.0)
+
+        train_losses.append(avg_train_loss)
+        test_losses.append(avg_test_loss)
+
+        old_lr = optimizer.param_groups[0]["lr"]
+        scheduler.step(avg_test_loss)
+        new_lr = optimizer.param_groups[0]["lr"]
+        if new_lr != old_lr:
+            logger.info(f"  Learning rate reduced: {old_lr:.6f} -> {new_lr:.6f}")
+
+        seconds = (datetime.now() - started).total_seconds()
+        logger.info(f"\nEpoch {epoch}/{num_epochs} - Duration: {seconds:.1f}s")
+        logger.info(f"  Train Loss: {avg_train_loss:.6f} ({config.LOSS_TYPE.upper()}: {avg_train_term:.6f})")
+        logger.info(f"  Test Loss:  {avg_test_loss:.6f} ({config.LOSS_TYPE.upper()}: {avg_test_term:.6f})")
+        logger.info(f"  Learning Rate: {new_lr:.6f}")
+
+        # early stopping watches the TRAIN loss (trainer.py:262-270)
+        if avg_train_loss < best_train_loss - config.MIN_DELTA:
+            logger.info(f"  Train loss improved by {best_train_loss - avg_train_loss:.6f}")
+            best_train_loss, best_epoch, stale_epochs = avg_train_loss, epoch, 0
+        else:
+            stale_epochs += 1
+            logger.info(f"  No train loss improvement for {stale_epochs} epoch(s)")
+
+        # best checkpoint watches the TEST loss (trainer.py:273-287)
+        if avg_test_loss < best_test_loss - config.MIN_DELTA:
+            gained = best_test_loss - avg_test_loss
+            best_test_loss = avg_test_loss
+            if is_main:
+                torch.save(checkpoint_payload(epoch, model, optimizer, avg_train_loss, avg_test_loss),
+                           config.CHECKPOINT_PATH / "best_model.pth")
+            logger.info(f"  New best model saved! (test loss improvement: {gained:.6f})")
+
+        if epoch % config.SAVE_EVERY_N_EPOCHS == 0 and is_main:
+            path = config.CHECKPOINT_PATH / f"checkpoint_epoch_{epoch}.pth"
+            torch.save(checkpoint_payload(epoch, model, optimizer, avg_train_loss, avg_test_loss), path)
+            kept_checkpoints.append(path)
+            logger.info(f"  Checkpoint saved: {path.name}")
+            if len(kept_checkpoints) > config.KEEP_LAST_N_CHECKPOINTS:
+                old = kept_checkpoints.pop(0)
+                if old.exists():
+                    old.unlink()
+                    logger.info(f"  Removed old checkpoint: {old.name}")
+
+        if device.type == "cuda" and epoch % 5 == 0:
+            torch.cuda.empty_cache()
+            gc.collect()
+
+        if stale_epochs >= config.PATIENCE:
+            logger.info(f"\nEARLY STOPPING at epoch {epoch}: no train loss improvement for {config.PATIENCE} epochs "
+                        f"(best train {best_train_loss:.6f} at epoch {best_epoch}, best test {best_test_loss:.6f})")
+            break
+
+    logger.info(f"\nTRAINING COMPLETE: {epoch} epochs, best train loss {best_train_loss:.6f} at epoch {best_epoch}, "
+                f"best test loss {best_test_loss:.6f}")
+
+    stamp = datetime.now().strftime("%Y%m%d_%H%M%S")
+    if is_main and train_losses:
+        plot_loss_curves(train_losses, test_losses, save_path=config.OUTPUT_PATH / f"loss_curves_{stamp}.png")
+    if world > 1:
+        dist.barrier()
+    best_path = config.CHECKPOINT_PATH / "best_model.pth"
+    if best_path.exists():
+        best = safe_torch_load(best_path, map_location=device)
+        unwrap(model).load_state_dict(best["model_state_dict"])
+        logger.info(f"Best model loaded from epoch {best['epoch']}")
+
+    history = {
+        "train_losses": train_losses, "test_losses": test_losses,
+        "best_train_loss": best_train_loss, "best_test_loss": best_test_loss,
+        "best_epoch": best_epoch, "total_epochs": epoch,
+        "config": {"num_epochs": num_epochs, "batch_size": batch_size, "learning_rate": learning_rate,
+                   "grid_size": grid},
+    }
+    if is_main:
+        history_path = config.OUTPUT_PATH / f"training_history_{stamp}.pth"
+        torch.save(history, history_path)
+        logger.info(f"Training history saved to {history_path}")
+    return unwrap(model), history
+
+
+# ------------------------------------------------------------------------------------------------
+# test_model
+# ------------------------------------------------------------------------------------------------
+
+def test_model(test_loader, model_path=None, batch_size=None, device=None, num_visualizations=5,
+               save_visualizations=True):
+    """Evaluate a checkpoint (trainer.py:394-711): loss, argmax accuracies, frames with events and a few
+    ground-truth-vs-prediction plots.  Accuracies and event counts are reduced on the device batch by
+    batch instead of collecting every logit on the host (N x 9 MB x 2 upstream); only the frames that
+    are actually plotted are copied back.  Runs on the calling rank only (rank 0 under torchrun)."""
+    batch_size = batch_size or config.BATCH_SIZE
+    model_path = Path(model_path or (config.CHECKPOINT_PATH / "best_model.pth"))
+    device = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    test_dataset = test_loader.dataset
+    grid = (test_dataset.I, test_dataset.J)
+    logger.info(f"Test dataset: {len(test_dataset)} windows ({len(test_loader)} batches)")
+    if not model_path.exists():
+        raise FileNotFoundError(f"Model checkpoint not found: {model_path}")
+    if get_rank() != 0:
+        logger.info("test_model runs on rank 0 only")
+        return {}
+
+    checkpoint = safe_torch_load(model_path, map_location=device)
+    model = prepare_model_for_device(build_model(grid, True), device)
+    model.load_state_dict(checkpoint["model_state_dict"])
+    model.eval()
+    logger.info(f"Model loaded (epoch {checkpoint['epoch']}, test loss {checkpoint['test_loss']:.6f})")
+    criterion = SMRSELDLoss(loss_type=config.LOSS_TYPE, w_class=config.W_CLASS, w_aiur=config.W_AIUR,
+                            w_cl=config.W_CL, grid_size=grid)          # un-weighted, trainer.py:483-489
+
+    feed = make_feed(test_loader, device, 0, 1)
+    bg = config.NUM_CLASSES - 1
+    loss_sum = torch.zeros((), dtype=torch.float64, device=device)
+    term_sum = torch.zeros((), dtype=torch.float64, device=device)
+    correct = torch.zeros((), dtype=torch.int64, device=device)
+    correct_events = torch.zeros((), dtype=torch.int64, device=device)
+    n_cells = torch.zeros((), dtype=torch.int64, device=device)
+    n_events = torch.zeros((), dtype=torch.int64, device=device)
+    active_per_frame = []                                     # [B, T] int32 per batch (small)
+    steps = 0
+    with torch.no_grad():
+        for spectrograms, labels in tqdm(feed.batches(0), total=len(feed), desc="Testing"):
+            predictions, total, term = eval_step(model, criterion, spectrograms, labels, device)
+            loss_sum += total.double()
+            term_sum += term.double()
+            steps += 1
+            pred_cls = predictions.argmax(dim=-1)
+            true_cls = _label_classes(labels, config.NUM_CLASSES)
+            events = true_cls != bg
+            hit = pred_cls == true_cls
+            correct += hit.sum()
+            correct_events += (hit & events).sum()
+            n_cells += hit.numel()
+            n_events += events.sum()
+            active_per_frame.append(events.sum(dim=-1).to(torch.int32).cpu())
+    avg_test_loss = loss_sum.item() / max(steps, 1)
+    avg_test_term = term_sum.item() / max(steps, 1)
+    overall_accuracy = 100.0 * correct.item() / max(n_cells.item(), 1)
+    non_bg_accuracy = 100.0 * correct_events.item() / n_events.item() if n_events.item() > 0 else 0.0
+    logger.info(f"Total Loss: {avg_test_loss:.6f}  (Class {config.LOSS_TYPE.upper()}: {avg_test_term:.6f})")
+    logger.info(f"Overall Accuracy: {overall_accuracy:.2f}%  Non-Background Accuracy: {non_bg_accuracy:.2f}%")
+    logger.info(f"Active Events: {n_events.item()} / {n_cells.item()}")
+
+    active = torch.cat(active_per_frame, dim=0) if active_per_frame else torch.zeros((0, 0), dtype=torch.int32)
+    frames_with_events = [(int(w), int(t), int(active[w, t])) for w, t in (active > 0).nonzero().tolist()]
+    logger.info(f"Found {len(frames_with_events)} frames with active events")
+    results = {
+        "test_loss": avg_test_loss, f"class_{config.LOSS_TYPE}": avg_test_term,
+        "overall_accuracy": overall_accuracy, "non_bg_accuracy": non_bg_accuracy,
+        "num_frames_with_events": len(frames_with_events), "visualizations": [],
+        "checkpoint_epoch": checkpoint["epoch"],
+    }
+    if not frames_with_events:
+        logger.warning("No frames with active events found! Cannot create visualizations.")
+        return results
+
+    chosen = random.sample(frames_with_events, min(num_visualizations, len(frames_with_events)))
+    chosen.sort(key=lambda f: f[2], reverse=True)
+    if save_visualizations:
+        (config.OUTPUT_PATH / "test_visualizations").mkdir(exist_ok=True)
+    for viz, (window_idx, time_idx, num_active) in enumerate(chosen, start=1):
+        spec, labels = test_dataset[window_idx]
+        with torch.no_grad(), autocast_context(device):
+            logits = model(spec.unsqueeze(0).to(device))[0, time_idx].float().cpu()
+        save_path = None
+        if save_visualizations:
+            save_path = config.OUTPUT_PATH / "test_visualizations" / f"test_viz_{viz}_window{window_idx}_frame{time_idx}.png"
+        fig = visualize_grid_predictions(ground_truth=labels[time_idx], predictions=logits, time_frame=time_idx,
+                                         grid_size=grid, title_prefix=f"Window {window_idx}, ", save_path=save_path)
+        results["visualizations"].append({"window_idx": window_idx, "time_idx": time_idx, "num_active": num_active,
+                                          "figure": fig, "save_path": save_path})
+    logger.info("TESTING COMPLETE")
+    return results
+
+
+def _label_classes(labels, num_classes):
+    """argmax over classes of the labels, for dense float labels or the compact uint16 mask
+    (lowest set bit = first maximal class, as torch.argmax picks the first maximum; mask 0 = background)."""
+    if labels.dtype != torch.uint16:
+        return labels.argmax(dim=-1)
+    m = labels.to(torch.int32)
+    lowest = (m & -m).float().log2().to(torch.int64)
+    return torch.where(m == 0, torch.full_like(lowest, num_classes - 1), lowest)
