@@ -54,6 +54,8 @@ def _declare(lib):
     lib.seld_softmax_mse_workspace_bytes.restype = _i64
     lib.seld_softmax_mse_workspace_bytes.argtypes = []
     lib.seld_softmax_mse.argtypes = [_ptr, _int, _ptr, _ptr, _i64, _int, ctypes.c_float, _ptr, _ptr, _ptr, _ptr]
+    lib.seld_gru_forward.argtypes = [_ptr, _int, _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr]
+    lib.seld_gru_backward.argtypes = [_ptr, _ptr, _ptr, _int, _ptr, _i64, _i64, _i64, _ptr, _ptr]
     return lib
 
 
@@ -263,3 +265,39 @@ def softmax_mse(logits: torch.Tensor, labels: torch.Tensor, grad_scale: float | 
                                               _p(_workspace(logits.device)), _stream_ptr(logits.device)),
               "seld_softmax_mse")
     return loss[0], grad
+
+
+# --------------------------------------------------------------------------- GRU recurrence
+
+def gru_forward(gi: torch.Tensor, w_hh: torch.Tensor, b_hh: torch.Tensor, need_saved: bool):
+    """gi [B, T, 2, 3H] (fp32 / bf16), w_hh [2, 3H, H], b_hh [2, 3H] -> (y [B, T, 2H], saved or None)."""
+    if not gi.is_cuda:
+        raise SeldNativeError("gru_forward: tensors must live on the GPU")
+    b, t, two, g3 = gi.shape
+    h = g3 // 3
+    if two != 2 or gi.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("gru_forward: gi must be [B, T, 2, 3H] float32 or bfloat16")
+    index = ensure_init(gi.device)
+    gi = gi.contiguous()
+    w = w_hh.to(torch.bfloat16).contiguous()
+    bias = b_hh.to(torch.float32).contiguous()
+    y = torch.empty((b, t, 2 * h), dtype=gi.dtype, device=gi.device)
+    saved = torch.empty((b, t, 2, 4, h), dtype=torch.float32, device=gi.device) if need_saved else None
+    with torch.cuda.device(index):
+        check(load_library().seld_gru_forward(_p(gi), int(gi.dtype == torch.bfloat16), _p(w), _p(bias), b, t, h,
+                                              _p(y), _p(saved), _stream_ptr(gi.device)), "seld_gru_forward")
+    return y, saved
+
+
+def gru_backward(dy: torch.Tensor, y: torch.Tensor, saved: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
+    """-> dg [B, T, 2, 4, H] (da_r, da_z, da_n, da_n*r), dtype of y."""
+    b, t, h2 = y.shape
+    h = h2 // 2
+    index = ensure_init(y.device)
+    dy = dy.to(y.dtype).contiguous()
+    w_t = w_hh.to(torch.bfloat16).transpose(1, 2).contiguous()            # [2, H, 3H]
+    dg = torch.empty((b, t, 2, 4, h), dtype=y.dtype, device=y.device)
+    with torch.cuda.device(index):
+        check(load_library().seld_gru_backward(_p(dy), _p(y), _p(saved), int(y.dtype == torch.bfloat16), _p(w_t),
+                                               b, t, h, _p(dg), _stream_ptr(y.device)), "seld_gru_backward")
+    return dg

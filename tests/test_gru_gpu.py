@@ -1,0 +1,86 @@
+"""GPU parity for the persistent BiGRU recurrence (csrc/gru.hip) through the C ABI.
+
+Oracle: oracle/gru.py -- an explicit-time-loop restatement of nn.GRU (pinned to torch.nn.GRU itself
+on the CPU to 1e-7) with the kernel's bf16 rounding points (W_hh and the h operand of the MFMA).
+Bars: <= 2e-3 abs against the bf16-aware oracle (values are in [-1, 1]); the distance to pure-fp32
+nn.GRU is the bf16 drift and is reported/bounded separately (north_star: "<= 1e-3 rel on logits"
+holds for fp32 runs, which keep nn.GRU).
+"""
+import pytest
+import torch
+
+from oracle import gru as ogru
+
+pytestmark = pytest.mark.gpu
+H = 256
+
+
+def _params(in_size, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    k = 1.0 / H ** 0.5
+    u = lambda *s: (torch.rand(*s, generator=g) * 2 - 1) * k * scale      # noqa: E731
+    return ([u(3 * H, in_size), u(3 * H, in_size)], [u(3 * H), u(3 * H)],
+            [u(3 * H, H) * 2.0, u(3 * H, H) * 2.0], [u(3 * H), u(3 * H)])
+
+
+@pytest.mark.parametrize("batch,steps", [(1, 1), (5, 7), (16, 33), (32, 250), (37, 20)])
+def test_forward_matches_bf16_aware_oracle(gpu_device, batch, steps):
+    import seld_native
+    w_ih, b_ih, w_hh, b_hh = _params(64, 1)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(batch, steps, 64, generator=g)
+    gi = torch.stack([torch.nn.functional.linear(x, w_ih[d], b_ih[d]) for d in range(2)], dim=2)   # [B,T,2,3H]
+    y, saved = seld_native.gru_forward(gi.to(gpu_device), torch.stack(w_hh).to(gpu_device),
+                                       torch.stack(b_hh).to(gpu_device), True)
+    ref = ogru.bigru_layer(x, w_ih, b_ih, w_hh, b_hh, exact=False)
+    assert tuple(y.shape) == (batch, steps, 2 * H) and tuple(saved.shape) == (batch, steps, 2, 4, H)
+    assert (y.cpu() - ref).abs().max().item() <= 2e-3
+    exact = ogru.bigru_layer(x, w_ih, b_ih, w_hh, b_hh, exact=True)
+    assert (y.cpu() - exact).abs().max().item() <= 3e-2          # bf16 drift of the recurrence
+
+
+def test_module_forward_and_backward(gpu_device):
+    """SeldGRU (nn.GRU parameters, HIP recurrence) against the oracle's autograd, one layer."""
+    import seld_gru
+    from seld_rnn import SeldGRU
+    torch.manual_seed(5)
+    m = SeldGRU(input_size=96, hidden_size=H, num_layers=1, batch_first=True, bidirectional=True).to(gpu_device)
+    x = torch.randn(6, 40, 96, device=gpu_device, requires_grad=True)
+    assert seld_gru.applicable(m, x)
+    y, h_n = m(x)
+    assert tuple(y.shape) == (6, 40, 2 * H) and tuple(h_n.shape) == (2, 6, H)
+    go = torch.randn_like(y)
+    (y * go).sum().backward()
+
+    cpu = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.named_parameters()}
+    xc = x.detach().cpu().clone().requires_grad_(True)
+    ref = ogru.bigru_layer(xc, [cpu["weight_ih_l0"], cpu["weight_ih_l0_reverse"]],
+                           [cpu["bias_ih_l0"], cpu["bias_ih_l0_reverse"]],
+                           [cpu["weight_hh_l0"], cpu["weight_hh_l0_reverse"]],
+                           [cpu["bias_hh_l0"], cpu["bias_hh_l0_reverse"]], exact=False)
+    assert (y.detach().cpu() - ref).abs().max().item() <= 2e-3
+    (ref * go.cpu()).sum().backward()
+
+    def close(a, b, name):
+        scale = b.abs().max().item()
+        err = (a.cpu() - b).abs().max().item()
+        assert err <= 3e-2 * scale + 1e-6, f"{name}: err {err:.3e} vs scale {scale:.3e}"
+    close(x.grad, xc.grad, "dx")
+    for name, p in m.named_parameters():
+        close(p.grad, cpu[name].grad, name)
+
+
+def test_two_layer_bf16_autocast_tracks_nn_gru(gpu_device):
+    from seld_rnn import SeldGRU
+    torch.manual_seed(7)
+    fused = SeldGRU(128, H, num_layers=2, batch_first=True, bidirectional=True, dropout=0.3).to(gpu_device).eval()
+    stock = torch.nn.GRU(128, H, num_layers=2, batch_first=True, bidirectional=True, dropout=0.3).to(gpu_device).eval()
+    stock.load_state_dict(fused.state_dict())
+    x = torch.randn(4, 250, 128, device=gpu_device)
+    with torch.no_grad():
+        ref, ref_h = stock(x)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            got, got_h = fused(x)
+    assert got.dtype == torch.bfloat16
+    assert (got.float() - ref).abs().max().item() <= 5e-2
+    assert (got_h.float() - ref_h).abs().max().item() <= 5e-2

@@ -105,7 +105,10 @@ def test_full_size_properties_60s_clip(gpu_device):
     assert (b - a - 10.0 * np.log10(4.0)).abs().max().item() <= 2e-5
     shifted = torch.cat([torch.zeros(4, 16 * 480, device=gpu_device), pcm[:, :-16 * 480]], dim=1)
     c = seld_native.logmel(shifted)
-    assert torch.equal(c[:, :, 18:3000], a[:, :, 2:2984])
+    # groups 0 and 187 run the reflect-capable load path (a different instantiation, whose fma
+    # contraction may differ): compare frames that use the interior path in both runs
+    assert torch.equal(c[:, :, 32:2976], a[:, :, 16:2960])
+    assert (c[:, :, 18:3000] - a[:, :, 2:2984]).abs().max().item() <= 2e-5
     rng = np.random.default_rng(0)
     frames = np.sort(rng.choice(np.arange(2, 2998), size=200, replace=False))
     host = pcm.cpu()
