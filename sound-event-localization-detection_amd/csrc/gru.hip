@@ -52,6 +52,25 @@ __device__ __forceinline__ float tanh_f(float x) {
   return (e - 1.0f) / (e + 1.0f);
 }
 
+// 4 consecutive hidden units of one sequence, as stored in global memory
+template <typename T> struct Vec4;
+template <> struct Vec4<float> { typedef float4 type; };
+template <> struct Vec4<__hip_bfloat16> { typedef uint2 type; };
+
+__device__ __forceinline__ void unpack4(const float4& v, float (&f)[4]) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
+__device__ __forceinline__ void unpack4(const uint2& v, float (&f)[4]) {
+  f[0] = __uint_as_float(v.x << 16);
+  f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16);
+  f[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  return static_cast<unsigned>(__bfloat16_as_ushort(__float2bfloat16(lo))) |
+         (static_cast<unsigned>(__bfloat16_as_ushort(__float2bfloat16(hi))) << 16);
+}
+__device__ __forceinline__ void pack4(const float (&f)[4], float4& v) { v = make_float4(f[0], f[1], f[2], f[3]); }
+__device__ __forceinline__ void pack4(const float (&f)[4], uint2& v) { v = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3])); }
+
 struct GruFwdArgs {
   const void* gi;        // [B][T][2][3H]   (x W_ih^T + b_ih, both directions)
   const __hip_bfloat16* w_hh;   // [2][3H][H]
@@ -61,8 +80,12 @@ struct GruFwdArgs {
   long B, T;
 };
 
+// The MFMA computes gh^T = W_hh h^T: M = gate rows (units), N = the 16 sequences of the tile.  With
+// D[m = 4q+i][n = c] lane (q, c) owns sequence c and the 4 CONSECUTIVE units 4q..4q+3 of each 16-unit
+// tile, so every global / LDS access of the gate math is an 8- or 16-byte vector.
 template <typename T>
 __global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs a) {
+  typedef typename Vec4<T>::type V4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16x8* wn_lds = reinterpret_cast<bf16x8*>(smem);
   __hip_bfloat16* hbuf = reinterpret_cast<__hip_bfloat16*>(smem + kWnBytes);   // [2][16][kHPitch]
@@ -77,12 +100,15 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs 
   const T* gi = static_cast<const T*>(a.gi);
   T* y = static_cast<T*>(a.y);
   float* saved = a.saved;
+  const long b = row0 + c;                 // this lane's sequence
+  const bool valid = b < a.B;
+  const long bb = valid ? b : 0;
 
-  // ---- resident weights: r,z gates -> registers, n gate -> LDS (fragment-major)
+  // ---- resident weights (A operand: row = unit l&15 of the tile, k = 8(l>>4)+j): r,z -> VGPRs, n -> LDS
   bf16x8 wr[2][8], wz[2][8];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int unit = 32 * wave + 16 * s + c;              // B-fragment column = gate row of this unit
+    const int unit = 32 * wave + 16 * s + c;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
       const int k0 = 32 * kk + 8 * q;
@@ -94,108 +120,115 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs 
   }
   for (int i = tid; i < 2 * kRows * kHPitch; i += kGruThreads) hbuf[i] = __float2bfloat16(0.0f);
 
-  float bias_r[2], bias_z[2], bias_n[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int unit = 32 * wave + 16 * s + c;
-    bias_r[s] = bh[unit];
-    bias_z[s] = bh[kH + unit];
-    bias_n[s] = bh[2 * kH + unit];
-  }
+  float bias[2][3][4];
   float h_prev[2][4];
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) h_prev[s][i] = 0.0f;
+    for (int i = 0; i < 4; ++i) {
+      const int unit = 32 * wave + 16 * s + 4 * q + i;
+      bias[s][0][i] = bh[unit];
+      bias[s][1][i] = bh[kH + unit];
+      bias[s][2][i] = bh[2 * kH + unit];
+      h_prev[s][i] = 0.0f;
+    }
   __syncthreads();
 
-  // gi of step `t` for this lane's (row 4q+i, unit) pairs: [s][gate][i]
-  auto load_gi = [&](long tt, float (&g)[2][3][4]) {
+  auto time_of = [&](long step) { return dir == 0 ? step : a.T - 1 - step; };
+  auto load_gi = [&](long step, V4 (&g)[2][3]) {
+    const T* p = gi + ((bb * a.T + time_of(step)) * 2 + dir) * kG + 32 * wave + 4 * q;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const long b = row0 + 4 * q + i;
-      const bool ok = b < a.B;
-      const T* p = gi + ((ok ? b : 0) * a.T + tt) * (2 * kG) + dir * kG;
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int unit = 32 * wave + 16 * s + c;
-#pragma unroll
-        for (int gate = 0; gate < 3; ++gate) g[s][gate][i] = ok ? to_float(p[gate * kH + unit]) : 0.0f;
-      }
-    }
+      for (int gate = 0; gate < 3; ++gate) g[s][gate] = *reinterpret_cast<const V4*>(p + gate * kH + 16 * s);
+  };
+  // Pull the cache lines of a future step towards L2: one dword per (sequence, gate) line of this wave.
+  auto touch_gi = [&](long step) -> unsigned {
+    if (lane >= 48) return 0u;
+    const long tb = row0 + lane / 3;
+    const T* p = gi + (((tb < a.B ? tb : 0) * a.T + time_of(step)) * 2 + dir) * kG + (lane % 3) * kH + 32 * wave;
+    return *reinterpret_cast<const volatile unsigned*>(p);
   };
 
-  float g_cur[2][3][4];
-  load_gi(dir == 0 ? 0 : a.T - 1, g_cur);
+  V4 g_cur[2][3], g_next[2][3];
+  load_gi(0, g_cur);
+  unsigned touched = 0u;
+#pragma unroll 1
+  for (long ahead = 1; ahead < 4 && ahead < a.T; ++ahead) touched ^= touch_gi(ahead);
 
+#pragma unroll 1
   for (long t = 0; t < a.T; ++t) {
-    const long tt = dir == 0 ? t : a.T - 1 - t;
+    const long tt = time_of(t);
     const int cur = static_cast<int>(t & 1), nxt = cur ^ 1;
-    float g_next[2][3][4];
-    if (t + 1 < a.T) load_gi(dir == 0 ? t + 1 : a.T - 2 - t, g_next);
-
-    // ---- gh = h W_hh^T : A fragments of h_{t-1} from LDS
-    const __hip_bfloat16* hrow = hbuf + (cur * kRows + c) * kHPitch + 8 * q;
+    if (t + 4 < a.T) touched ^= touch_gi(t + 4);
+    if (t + 1 < a.T) load_gi(t + 1, g_next);
 
     f32x4 acc_r[2], acc_z[2], acc_n[2];
+    float gin[2][4];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
+      float gr[4], gz[4];
+      unpack4(g_cur[s][0], gr);
+      unpack4(g_cur[s][1], gz);
+      unpack4(g_cur[s][2], gin[s]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        acc_r[s][i] = g_cur[s][0][i] + bias_r[s];
-        acc_z[s][i] = g_cur[s][1][i] + bias_z[s];
-        acc_n[s][i] = bias_n[s];
+        acc_r[s][i] = gr[i] + bias[s][0][i];
+        acc_z[s][i] = gz[i] + bias[s][1][i];
+        acc_n[s][i] = bias[s][2][i];
       }
     }
+    // ---- gh^T = W_hh h^T : B fragments (k, n = sequence c) of h_{t-1} from LDS
+    const __hip_bfloat16* hrow = hbuf + (cur * kRows + c) * kHPitch + 8 * q;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-      const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(hrow + 32 * kk);
+      const bf16x8 hfrag = *reinterpret_cast<const bf16x8*>(hrow + 32 * kk);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        acc_r[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, wr[s][kk], acc_r[s], 0, 0, 0);
-        acc_z[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, wz[s][kk], acc_z[s], 0, 0, 0);
+        acc_r[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[s][kk], hfrag, acc_r[s], 0, 0, 0);
+        acc_z[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wz[s][kk], hfrag, acc_z[s], 0, 0, 0);
         const bf16x8 wn = wn_lds[((wave * 2 + s) * 8 + kk) * 64 + lane];
-        acc_n[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, wn, acc_n[s], 0, 0, 0);
+        acc_n[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn, hfrag, acc_n[s], 0, 0, 0);
       }
     }
 
-    // ---- gates (lane-local) and state update
+    // ---- gates (lane-local: sequence c, units 4q..4q+3 of each tile) and state update
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const int unit = 32 * wave + 16 * s + c;
+      const int unit0 = 32 * wave + 16 * s + 4 * q;
+      float rr[4], zz[4], nn[4], gg[4], hh[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float r = sigmoid_f(acc_r[s][i]);
-        const float z = sigmoid_f(acc_z[s][i]);
-        const float ghn = acc_n[s][i];
-        const float n = tanh_f(fmaf(r, ghn, g_cur[s][2][i]));
-        const float h = fmaf(z, h_prev[s][i] - n, n);
-        h_prev[s][i] = h;
-        const int row = 4 * q + i;
-        hbuf[(nxt * kRows + row) * kHPitch + unit] = __float2bfloat16(h);
-        const long b = row0 + row;
-        if (b < a.B) {
-          y[(b * a.T + tt) * (2 * kH) + dir * kH + unit] = from_float<T>(h);
-          if (saved) {
-            float* sp = saved + (((b * a.T + tt) * 2 + dir) * 4) * kH + unit;
-            sp[0] = r;
-            sp[kH] = z;
-            sp[2 * kH] = n;
-            sp[3 * kH] = ghn;
-          }
+        rr[i] = sigmoid_f(acc_r[s][i]);
+        zz[i] = sigmoid_f(acc_z[s][i]);
+        gg[i] = acc_n[s][i];
+        nn[i] = tanh_f(fmaf(rr[i], gg[i], gin[s][i]));
+        hh[i] = fmaf(zz[i], h_prev[s][i] - nn[i], nn[i]);
+        h_prev[s][i] = hh[i];
+      }
+      uint2 hb;
+      pack4(hh, hb);
+      *reinterpret_cast<uint2*>(hbuf + (nxt * kRows + c) * kHPitch + unit0) = hb;
+      if (valid) {
+        V4 yv;
+        pack4(hh, yv);
+        *reinterpret_cast<V4*>(y + (b * a.T + tt) * (2 * kH) + dir * kH + unit0) = yv;
+        if (saved) {
+          float* sp = saved + (((b * a.T + tt) * 2 + dir) * 4) * kH + unit0;
+          *reinterpret_cast<float4*>(sp) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+          *reinterpret_cast<float4*>(sp + kH) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+          *reinterpret_cast<float4*>(sp + 2 * kH) = make_float4(nn[0], nn[1], nn[2], nn[3]);
+          *reinterpret_cast<float4*>(sp + 3 * kH) = make_float4(gg[0], gg[1], gg[2], gg[3]);
         }
       }
     }
     __syncthreads();
-    if (t + 1 < a.T) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int gate = 0; gate < 3; ++gate)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) g_cur[s][gate][i] = g_next[s][gate][i];
-    }
+      for (int gate = 0; gate < 3; ++gate) g_cur[s][gate] = g_next[s][gate];
   }
+  asm volatile("" ::"v"(touched));
 }
 
 struct GruBwdArgs {
@@ -207,8 +240,10 @@ struct GruBwdArgs {
   long B, T;
 };
 
+// dh_prev^T = W_hh^T dgh^T : M = hidden units, N = sequences; same lane ownership as the forward kernel.
 template <typename T>
 __global__ __launch_bounds__(kGruThreads, 2) void gru_backward_kernel(GruBwdArgs a) {
+  typedef typename Vec4<T>::type V4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16x8* wn_lds = reinterpret_cast<bf16x8*>(smem);                               // k-range of the n gate
   __hip_bfloat16* dgh = reinterpret_cast<__hip_bfloat16*>(smem + kWnBytes);       // [16][kDghPitch]
@@ -223,8 +258,10 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_backward_kernel(GruBwdArgs
   const T* y = static_cast<const T*>(a.y);
   const float* saved = a.saved;
   T* dg = static_cast<T*>(a.dg);
+  const long b = row0 + c;
+  const bool valid = b < a.B;
+  const long bb = valid ? b : 0;
 
-  // dh_prev[m][u] = sum_k dgh[m][k] W_hh[k][u]: B fragment (k, n=u) = W_hh^T[u][k..k+7]
   bf16x8 wrz[2][16];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -244,43 +281,93 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_backward_kernel(GruBwdArgs
     for (int i = 0; i < 4; ++i) dh[s][i] = 0.0f;
   __syncthreads();
 
+  auto time_of = [&](long step) { return dir == 0 ? step : a.T - 1 - step; };
+  struct StepIn { float4 r[2], z[2], n[2], g[2]; V4 hp[2], d[2]; };
+  auto load_step = [&](long step, StepIn& in) {
+    const long tt = time_of(step);
+    const float* sp = saved + (((bb * a.T + tt) * 2 + dir) * 4) * kH + 32 * wave + 4 * q;
+    const T* dp = dy + (bb * a.T + tt) * (2 * kH) + dir * kH + 32 * wave + 4 * q;
+    const long tprev = dir == 0 ? tt - 1 : tt + 1;
+    const T* hp = y + (bb * a.T + (step > 0 ? tprev : tt)) * (2 * kH) + dir * kH + 32 * wave + 4 * q;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      in.r[s] = *reinterpret_cast<const float4*>(sp + 16 * s);
+      in.z[s] = *reinterpret_cast<const float4*>(sp + kH + 16 * s);
+      in.n[s] = *reinterpret_cast<const float4*>(sp + 2 * kH + 16 * s);
+      in.g[s] = *reinterpret_cast<const float4*>(sp + 3 * kH + 16 * s);
+      in.d[s] = *reinterpret_cast<const V4*>(dp + 16 * s);
+      in.hp[s] = *reinterpret_cast<const V4*>(hp + 16 * s);
+    }
+  };
+  auto touch_step = [&](long step) -> unsigned {
+    const long tb = row0 + (lane >> 2);
+    const long tt = time_of(step);
+    const float* sp = saved + ((((tb < a.B ? tb : 0) * a.T + tt) * 2 + dir) * 4 + (lane & 3)) * kH + 32 * wave;
+    unsigned v = *reinterpret_cast<const volatile unsigned*>(sp);
+    if (lane < 32) {
+      const long rb = row0 + (lane & 15);
+      const long tprev = dir == 0 ? tt - 1 : tt + 1;
+      const T* base = lane < 16 ? dy : y;
+      const long tsel = lane < 16 ? tt : (step > 0 ? tprev : tt);
+      v ^= *reinterpret_cast<const volatile unsigned*>(base + ((rb < a.B ? rb : 0) * a.T + tsel) * (2 * kH) + dir * kH + 32 * wave);
+    }
+    return v;
+  };
+
+  StepIn cur_in, next_in;
+  load_step(a.T - 1, cur_in);
+  unsigned touched = 0u;
+#pragma unroll 1
+  for (long back = 2; back < 5 && a.T - back >= 0; ++back) touched ^= touch_step(a.T - back);
+
+#pragma unroll 1
   for (long t = a.T - 1; t >= 0; --t) {            // reverse of the forward processing order
-    const long tt = dir == 0 ? t : a.T - 1 - t;
-    const long tprev = dir == 0 ? tt - 1 : tt + 1;  // time index of h_{t-1} in the forward recurrence
-    const bool has_prev = t > 0;
+    const long tt = time_of(t);
+    if (t - 4 >= 0) touched ^= touch_step(t - 4);
+    if (t > 0) load_step(t - 1, next_in);
     float keep[2][4];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const int unit = 32 * wave + 16 * s + c;
+      const int unit0 = 32 * wave + 16 * s + 4 * q;
+      float r[4], z[4], n[4], g[4], hp[4], d[4], da_r[4], da_z[4], da_n[4], dghn[4];
+      unpack4(cur_in.r[s], r);
+      unpack4(cur_in.z[s], z);
+      unpack4(cur_in.n[s], n);
+      unpack4(cur_in.g[s], g);
+      unpack4(cur_in.hp[s], hp);
+      unpack4(cur_in.d[s], d);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int row = 4 * q + i;
-        const long b = row0 + row;
-        float da_r = 0.0f, da_z = 0.0f, da_n = 0.0f, dghn = 0.0f, carry = 0.0f;
-        if (b < a.B) {
-          const float* sp = saved + (((b * a.T + tt) * 2 + dir) * 4) * kH + unit;
-          const float r = sp[0], z = sp[kH], n = sp[2 * kH], ghn = sp[3 * kH];
-          const float hp = has_prev ? to_float(y[(b * a.T + tprev) * (2 * kH) + dir * kH + unit]) : 0.0f;
-          const float dtot = to_float(dy[(b * a.T + tt) * (2 * kH) + dir * kH + unit]) + dh[s][i];
-          const float dn = dtot * (1.0f - z);
-          const float dz = dtot * (hp - n);
-          da_n = dn * (1.0f - n * n);
-          da_z = dz * z * (1.0f - z);
-          da_r = da_n * ghn * r * (1.0f - r);
-          dghn = da_n * r;
-          carry = dtot * z;
-          T* gp = dg + (((b * a.T + tt) * 2 + dir) * 4) * kH + unit;
-          gp[0] = from_float<T>(da_r);
-          gp[kH] = from_float<T>(da_z);
-          gp[2 * kH] = from_float<T>(da_n);
-          gp[3 * kH] = from_float<T>(dghn);
-        }
-        keep[s][i] = carry;
-        __hip_bfloat16* drow = dgh + row * kDghPitch + unit;
-        drow[0] = __float2bfloat16(da_r);
-        drow[kH] = __float2bfloat16(da_z);
-        drow[2 * kH] = __float2bfloat16(dghn);
+        const float hprev = t > 0 ? hp[i] : 0.0f;
+        const float dtot = valid ? d[i] + dh[s][i] : 0.0f;
+        const float dn = dtot * (1.0f - z[i]);
+        const float dz = dtot * (hprev - n[i]);
+        da_n[i] = dn * (1.0f - n[i] * n[i]);
+        da_z[i] = dz * z[i] * (1.0f - z[i]);
+        da_r[i] = da_n[i] * g[i] * r[i] * (1.0f - r[i]);
+        dghn[i] = da_n[i] * r[i];
+        keep[s][i] = dtot * z[i];
       }
+      if (valid) {
+        T* gp = dg + (((b * a.T + tt) * 2 + dir) * 4) * kH + unit0;
+        V4 v;
+        pack4(da_r, v);
+        *reinterpret_cast<V4*>(gp) = v;
+        pack4(da_z, v);
+        *reinterpret_cast<V4*>(gp + kH) = v;
+        pack4(da_n, v);
+        *reinterpret_cast<V4*>(gp + 2 * kH) = v;
+        pack4(dghn, v);
+        *reinterpret_cast<V4*>(gp + 3 * kH) = v;
+      }
+      __hip_bfloat16* drow = dgh + c * kDghPitch + unit0;
+      uint2 pk;
+      pack4(da_r, pk);
+      *reinterpret_cast<uint2*>(drow) = pk;
+      pack4(da_z, pk);
+      *reinterpret_cast<uint2*>(drow + kH) = pk;
+      pack4(dghn, pk);
+      *reinterpret_cast<uint2*>(drow + 2 * kH) = pk;
     }
     __syncthreads();
 
@@ -289,14 +376,14 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_backward_kernel(GruBwdArgs
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[s][i] = keep[s][i];
-    const __hip_bfloat16* arow = dgh + c * kDghPitch + 8 * q;
+    const __hip_bfloat16* brow = dgh + c * kDghPitch + 8 * q;
 #pragma unroll
     for (int kk = 0; kk < 24; ++kk) {
-      const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(arow + 32 * kk);
+      const bf16x8 dfrag = *reinterpret_cast<const bf16x8*>(brow + 32 * kk);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const bf16x8 bfrag = kk < 16 ? wrz[s][kk < 16 ? kk : 0] : wn_lds[((wave * 2 + s) * 8 + (kk - 16)) * 64 + lane];
-        acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag, acc[s], 0, 0, 0);
+        const bf16x8 wfrag = kk < 16 ? wrz[s][kk < 16 ? kk : 0] : wn_lds[((wave * 2 + s) * 8 + (kk - 16)) * 64 + lane];
+        acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag, dfrag, acc[s], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -304,7 +391,9 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_backward_kernel(GruBwdArgs
 #pragma unroll
       for (int i = 0; i < 4; ++i) dh[s][i] = acc[s][i];
     __syncthreads();
+    cur_in = next_in;
   }
+  asm volatile("" ::"v"(touched));
 }
 
 }  // namespace seld

@@ -1,9 +1,14 @@
 #!/bin/bash
-# rocprofv3 kernel-trace of the benchmark (run on the GPU box): summaries land in gpurun_out/prof_<tag>/
+# rocprofv3 kernel-trace of the benchmark (run on the GPU box).  Only the per-kernel summary is kept
+# (the raw trace of ~100k dispatches is far over gpurun's 64 MiB return limit).
 set -e
 TAG=${1:-r01}
+shift || true
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
-mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_stdout.log 2>&1
-ls -R $OUT | head -20
+RAW=/tmp/prof_raw_$TAG
+rm -rf $RAW && mkdir -p $OUT $RAW
+rocprofv3 --kernel-trace --stats --output-format csv -d $RAW -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench_stdout.log 2>&1
+find $RAW -name "*kernel_stats.csv" -exec cp {} $OUT/ \;
+find $RAW -name "*kernel_trace.csv" -exec sh -c 'head -1 "$1" > '$OUT'/kernel_trace_logmel_gru.csv; grep -E "logmel|gru_|softmax_mse|rasterise|gather_rows|expand_kernel" "$1" | head -400 >> '$OUT'/kernel_trace_logmel_gru.csv' _ {} \;
+ls -la $OUT
