@@ -45,11 +45,12 @@ template <typename T> __device__ __forceinline__ T from_float(float v);
 template <> __device__ __forceinline__ float from_float<float>(float v) { return v; }
 template <> __device__ __forceinline__ __hip_bfloat16 from_float<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 / v_rcp_f32 (1 ulp) instead of the IEEE division sequence: the gates are fp32 but not bit-critical
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_f(float x) {
   const float c = fminf(fmaxf(x, -15.0f), 15.0f);
   const float e = __expf(2.0f * c);
-  return (e - 1.0f) / (e + 1.0f);
+  return (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
 // 4 consecutive hidden units of one sequence, as stored in global memory
@@ -83,42 +84,26 @@ struct GruFwdArgs {
 // The MFMA computes gh^T = W_hh h^T: M = gate rows (units), N = the 16 sequences of the tile.  With
 // D[m = 4q+i][n = c] lane (q, c) owns sequence c and the 4 CONSECUTIVE units 4q..4q+3 of each 16-unit
 // tile, so every global / LDS access of the gate math is an 8- or 16-byte vector.
-template <typename T>
-__global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs a) {
+//
+// kFull (all 16 sequences of the tile exist) and kSave are compile-time so that the step body has NO
+// divergent control flow around its stores: the compiler can then count outstanding stores and wait with
+// vmcnt(N) for the prefetched operands only, instead of draining every store each step (vmcnt(0)).
+template <typename T, bool kFull, bool kSave>
+__device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* wn_lds, __hip_bfloat16* hbuf,
+                                                  const bf16x8 (&wr)[2][8], const bf16x8 (&wz)[2][8]) {
   typedef typename Vec4<T>::type V4;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16x8* wn_lds = reinterpret_cast<bf16x8*>(smem);
-  __hip_bfloat16* hbuf = reinterpret_cast<__hip_bfloat16*>(smem + kWnBytes);   // [2][16][kHPitch]
-
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int q = lane >> 4, c = lane & 15;
   const int dir = blockIdx.y;
   const long row0 = static_cast<long>(blockIdx.x) * kRows;
-  const __hip_bfloat16* w = a.w_hh + static_cast<long>(dir) * kG * kH;
   const float* bh = a.b_hh + dir * kG;
   const T* gi = static_cast<const T*>(a.gi);
   T* y = static_cast<T*>(a.y);
   float* saved = a.saved;
   const long b = row0 + c;                 // this lane's sequence
-  const bool valid = b < a.B;
-  const long bb = valid ? b : 0;
-
-  // ---- resident weights (A operand: row = unit l&15 of the tile, k = 8(l>>4)+j): r,z -> VGPRs, n -> LDS
-  bf16x8 wr[2][8], wz[2][8];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int unit = 32 * wave + 16 * s + c;
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      const int k0 = 32 * kk + 8 * q;
-      wr[s][kk] = *reinterpret_cast<const bf16x8*>(w + static_cast<long>(unit) * kH + k0);
-      wz[s][kk] = *reinterpret_cast<const bf16x8*>(w + static_cast<long>(kH + unit) * kH + k0);
-      wn_lds[((wave * 2 + s) * 8 + kk) * 64 + lane] =
-          *reinterpret_cast<const bf16x8*>(w + static_cast<long>(2 * kH + unit) * kH + k0);
-    }
-  }
-  for (int i = tid; i < 2 * kRows * kHPitch; i += kGruThreads) hbuf[i] = __float2bfloat16(0.0f);
+  const bool valid = kFull || b < a.B;
+  const long bb = valid ? b : 0;           // rows past the batch compute on row 0's data and store nothing
 
   float bias[2][3][4];
   float h_prev[2][4];
@@ -132,7 +117,6 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs 
       bias[s][2][i] = bh[2 * kH + unit];
       h_prev[s][i] = 0.0f;
     }
-  __syncthreads();
 
   auto time_of = [&](long step) { return dir == 0 ? step : a.T - 1 - step; };
   auto load_gi = [&](long step, V4 (&g)[2][3]) {
@@ -142,26 +126,11 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs 
 #pragma unroll
       for (int gate = 0; gate < 3; ++gate) g[s][gate] = *reinterpret_cast<const V4*>(p + gate * kH + 16 * s);
   };
-  // Pull the cache lines of a future step towards L2: one dword per (sequence, gate) line of this wave.
-  auto touch_gi = [&](long step) -> unsigned {
-    if (lane >= 48) return 0u;
-    const long tb = row0 + lane / 3;
-    const T* p = gi + (((tb < a.B ? tb : 0) * a.T + time_of(step)) * 2 + dir) * kG + (lane % 3) * kH + 32 * wave;
-    return *reinterpret_cast<const volatile unsigned*>(p);
-  };
 
-  V4 g_cur[2][3], g_next[2][3];
-  load_gi(0, g_cur);
-  unsigned touched = 0u;
-#pragma unroll 1
-  for (long ahead = 1; ahead < 4 && ahead < a.T; ++ahead) touched ^= touch_gi(ahead);
-
-#pragma unroll 1
-  for (long t = 0; t < a.T; ++t) {
+  auto step = [&](long t, const V4 (&g_cur)[2][3], V4 (&g_next)[2][3]) {
     const long tt = time_of(t);
     const int cur = static_cast<int>(t & 1), nxt = cur ^ 1;
-    if (t + 4 < a.T) touched ^= touch_gi(t + 4);
-    if (t + 1 < a.T) load_gi(t + 1, g_next);
+    if (t + 1 < a.T) load_gi(t + 1, g_next);           // operands of the next step: one full step of cover
 
     f32x4 acc_r[2], acc_z[2], acc_n[2];
     float gin[2][4];
@@ -191,7 +160,6 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs 
         acc_n[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn, hfrag, acc_n[s], 0, 0, 0);
       }
     }
-
     // ---- gates (lane-local: sequence c, units 4q..4q+3 of each tile) and state update
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -209,11 +177,11 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs 
       uint2 hb;
       pack4(hh, hb);
       *reinterpret_cast<uint2*>(hbuf + (nxt * kRows + c) * kHPitch + unit0) = hb;
-      if (valid) {
+      if (kFull || valid) {
         V4 yv;
         pack4(hh, yv);
         *reinterpret_cast<V4*>(y + (b * a.T + tt) * (2 * kH) + dir * kH + unit0) = yv;
-        if (saved) {
+        if (kSave) {
           float* sp = saved + (((b * a.T + tt) * 2 + dir) * 4) * kH + unit0;
           *reinterpret_cast<float4*>(sp) = make_float4(rr[0], rr[1], rr[2], rr[3]);
           *reinterpret_cast<float4*>(sp + kH) = make_float4(zz[0], zz[1], zz[2], zz[3]);
@@ -223,12 +191,52 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs 
       }
     }
     __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int gate = 0; gate < 3; ++gate) g_cur[s][gate] = g_next[s][gate];
+  };
+
+  V4 g_a[2][3], g_b[2][3];                 // ping-pong operand sets (no register copies -> no forced waits)
+  load_gi(0, g_a);
+#pragma unroll 1
+  for (long t = 0; t < a.T; t += 2) {
+    step(t, g_a, g_b);
+    if (t + 1 < a.T) step(t + 1, g_b, g_a);
   }
-  asm volatile("" ::"v"(touched));
+}
+
+template <typename T>
+__global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16x8* wn_lds = reinterpret_cast<bf16x8*>(smem);
+  __hip_bfloat16* hbuf = reinterpret_cast<__hip_bfloat16*>(smem + kWnBytes);   // [2][16][kHPitch]
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int q = lane >> 4, c = lane & 15;
+  const __hip_bfloat16* w = a.w_hh + static_cast<long>(blockIdx.y) * kG * kH;
+
+  // ---- resident weights (A operand: row = unit l&15 of the tile, k = 8(l>>4)+j): r,z -> VGPRs, n -> LDS
+  bf16x8 wr[2][8], wz[2][8];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int unit = 32 * wave + 16 * s + c;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int k0 = 32 * kk + 8 * q;
+      wr[s][kk] = *reinterpret_cast<const bf16x8*>(w + static_cast<long>(unit) * kH + k0);
+      wz[s][kk] = *reinterpret_cast<const bf16x8*>(w + static_cast<long>(kH + unit) * kH + k0);
+      wn_lds[((wave * 2 + s) * 8 + kk) * 64 + lane] =
+          *reinterpret_cast<const bf16x8*>(w + static_cast<long>(2 * kH + unit) * kH + k0);
+    }
+  }
+  for (int i = tid; i < 2 * kRows * kHPitch; i += kGruThreads) hbuf[i] = __float2bfloat16(0.0f);
+  __syncthreads();
+
+  const bool full = static_cast<long>(blockIdx.x) * kRows + kRows <= a.B;     // workgroup-uniform
+  if (a.saved) {
+    if (full) gru_forward_steps<T, true, true>(a, wn_lds, hbuf, wr, wz);
+    else gru_forward_steps<T, false, true>(a, wn_lds, hbuf, wr, wz);
+  } else {
+    if (full) gru_forward_steps<T, true, false>(a, wn_lds, hbuf, wr, wz);
+    else gru_forward_steps<T, false, false>(a, wn_lds, hbuf, wr, wz);
+  }
 }
 
 struct GruBwdArgs {
@@ -240,50 +248,37 @@ struct GruBwdArgs {
   long B, T;
 };
 
-// dh_prev^T = W_hh^T dgh^T : M = hidden units, N = sequences; same lane ownership as the forward kernel.
-template <typename T>
-__global__ __launch_bounds__(kGruThreads, 2) void gru_backward_kernel(GruBwdArgs a) {
-  typedef typename Vec4<T>::type V4;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16x8* wn_lds = reinterpret_cast<bf16x8*>(smem);                               // k-range of the n gate
-  __hip_bfloat16* dgh = reinterpret_cast<__hip_bfloat16*>(smem + kWnBytes);       // [16][kDghPitch]
+template <typename T> struct GruStepIn {
+  float4 r[2], z[2], n[2], g[2];
+  typename Vec4<T>::type hp[2], d[2];
+};
 
+// dh_prev^T = W_hh^T dgh^T : M = hidden units, N = sequences; same lane ownership as the forward kernel.
+template <typename T, bool kFull>
+__device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* wn_lds, __hip_bfloat16* dgh,
+                                                   const bf16x8 (&wrz)[2][16]) {
+  typedef typename Vec4<T>::type V4;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int q = lane >> 4, c = lane & 15;
   const int dir = blockIdx.y;
   const long row0 = static_cast<long>(blockIdx.x) * kRows;
-  const __hip_bfloat16* wt = a.w_hh_t + static_cast<long>(dir) * kH * kG;         // [H][3H]
   const T* dy = static_cast<const T*>(a.dy);
   const T* y = static_cast<const T*>(a.y);
   const float* saved = a.saved;
   T* dg = static_cast<T*>(a.dg);
   const long b = row0 + c;
-  const bool valid = b < a.B;
+  const bool valid = kFull || b < a.B;
   const long bb = valid ? b : 0;
 
-  bf16x8 wrz[2][16];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int unit = 32 * wave + 16 * s + c;
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk)
-      wrz[s][kk] = *reinterpret_cast<const bf16x8*>(wt + static_cast<long>(unit) * kG + 32 * kk + 8 * q);
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk)
-      wn_lds[((wave * 2 + s) * 8 + kk) * 64 + lane] =
-          *reinterpret_cast<const bf16x8*>(wt + static_cast<long>(unit) * kG + 2 * kH + 32 * kk + 8 * q);
-  }
   float dh[2][4];
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int i = 0; i < 4; ++i) dh[s][i] = 0.0f;
-  __syncthreads();
 
   auto time_of = [&](long step) { return dir == 0 ? step : a.T - 1 - step; };
-  struct StepIn { float4 r[2], z[2], n[2], g[2]; V4 hp[2], d[2]; };
-  auto load_step = [&](long step, StepIn& in) {
+  auto load_step = [&](long step, GruStepIn<T>& in) {
     const long tt = time_of(step);
     const float* sp = saved + (((bb * a.T + tt) * 2 + dir) * 4) * kH + 32 * wave + 4 * q;
     const T* dp = dy + (bb * a.T + tt) * (2 * kH) + dir * kH + 32 * wave + 4 * q;
@@ -299,31 +294,9 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_backward_kernel(GruBwdArgs
       in.hp[s] = *reinterpret_cast<const V4*>(hp + 16 * s);
     }
   };
-  auto touch_step = [&](long step) -> unsigned {
-    const long tb = row0 + (lane >> 2);
-    const long tt = time_of(step);
-    const float* sp = saved + ((((tb < a.B ? tb : 0) * a.T + tt) * 2 + dir) * 4 + (lane & 3)) * kH + 32 * wave;
-    unsigned v = *reinterpret_cast<const volatile unsigned*>(sp);
-    if (lane < 32) {
-      const long rb = row0 + (lane & 15);
-      const long tprev = dir == 0 ? tt - 1 : tt + 1;
-      const T* base = lane < 16 ? dy : y;
-      const long tsel = lane < 16 ? tt : (step > 0 ? tprev : tt);
-      v ^= *reinterpret_cast<const volatile unsigned*>(base + ((rb < a.B ? rb : 0) * a.T + tsel) * (2 * kH) + dir * kH + 32 * wave);
-    }
-    return v;
-  };
 
-  StepIn cur_in, next_in;
-  load_step(a.T - 1, cur_in);
-  unsigned touched = 0u;
-#pragma unroll 1
-  for (long back = 2; back < 5 && a.T - back >= 0; ++back) touched ^= touch_step(a.T - back);
-
-#pragma unroll 1
-  for (long t = a.T - 1; t >= 0; --t) {            // reverse of the forward processing order
+  auto step = [&](long t, const GruStepIn<T>& cur_in, GruStepIn<T>& next_in) {
     const long tt = time_of(t);
-    if (t - 4 >= 0) touched ^= touch_step(t - 4);
     if (t > 0) load_step(t - 1, next_in);
     float keep[2][4];
 #pragma unroll
@@ -348,7 +321,7 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_backward_kernel(GruBwdArgs
         dghn[i] = da_n[i] * r[i];
         keep[s][i] = dtot * z[i];
       }
-      if (valid) {
+      if (kFull || valid) {
         T* gp = dg + (((b * a.T + tt) * 2 + dir) * 4) * kH + unit0;
         V4 v;
         pack4(da_r, v);
@@ -391,9 +364,42 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_backward_kernel(GruBwdArgs
 #pragma unroll
       for (int i = 0; i < 4; ++i) dh[s][i] = acc[s][i];
     __syncthreads();
-    cur_in = next_in;
+  };
+
+  GruStepIn<T> in_a, in_b;
+  load_step(a.T - 1, in_a);
+#pragma unroll 1
+  for (long t = a.T - 1; t >= 0; t -= 2) {       // reverse of the forward processing order
+    step(t, in_a, in_b);
+    if (t - 1 >= 0) step(t - 1, in_b, in_a);
   }
-  asm volatile("" ::"v"(touched));
+}
+
+template <typename T>
+__global__ __launch_bounds__(kGruThreads, 2) void gru_backward_kernel(GruBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16x8* wn_lds = reinterpret_cast<bf16x8*>(smem);                               // k-range of the n gate
+  __hip_bfloat16* dgh = reinterpret_cast<__hip_bfloat16*>(smem + kWnBytes);       // [16][kDghPitch]
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int q = lane >> 4, c = lane & 15;
+  const __hip_bfloat16* wt = a.w_hh_t + static_cast<long>(blockIdx.y) * kH * kG;  // [H][3H]
+
+  bf16x8 wrz[2][16];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int unit = 32 * wave + 16 * s + c;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+      wrz[s][kk] = *reinterpret_cast<const bf16x8*>(wt + static_cast<long>(unit) * kG + 32 * kk + 8 * q);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+      wn_lds[((wave * 2 + s) * 8 + kk) * 64 + lane] =
+          *reinterpret_cast<const bf16x8*>(wt + static_cast<long>(unit) * kG + 2 * kH + 32 * kk + 8 * q);
+  }
+  __syncthreads();
+  if (static_cast<long>(blockIdx.x) * kRows + kRows <= a.B) gru_backward_steps<T, true>(a, wn_lds, dgh, wrz);
+  else gru_backward_steps<T, false>(a, wn_lds, dgh, wrz);
 }
 
 }  // namespace seld
