@@ -130,7 +130,9 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
   auto step = [&](long t, const V4 (&g_cur)[2][3], V4 (&g_next)[2][3]) {
     const long tt = time_of(t);
     const int cur = static_cast<int>(t & 1), nxt = cur ^ 1;
-    if (t + 1 < a.T) load_gi(t + 1, g_next);           // operands of the next step: one full step of cover
+    // operands of the next step, one full step of cover.  Unconditional (index clamped at the last step):
+    // a branch here would make the compiler lose count of the outstanding loads and wait vmcnt(0) at once.
+    load_gi(t + 1 < a.T ? t + 1 : a.T - 1, g_next);
 
     f32x4 acc_r[2], acc_z[2], acc_n[2];
     float gin[2][4];
@@ -196,10 +198,11 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
   V4 g_a[2][3], g_b[2][3];                 // ping-pong operand sets (no register copies -> no forced waits)
   load_gi(0, g_a);
 #pragma unroll 1
-  for (long t = 0; t < a.T; t += 2) {
+  for (long t = 0; t + 1 < a.T; t += 2) {    // branch-free steady state: two steps per trip
     step(t, g_a, g_b);
-    if (t + 1 < a.T) step(t + 1, g_b, g_a);
+    step(t + 1, g_b, g_a);
   }
+  if (a.T & 1) step(a.T - 1, g_a, g_b);
 }
 
 template <typename T>
@@ -297,7 +300,7 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
 
   auto step = [&](long t, const GruStepIn<T>& cur_in, GruStepIn<T>& next_in) {
     const long tt = time_of(t);
-    if (t > 0) load_step(t - 1, next_in);
+    load_step(t > 0 ? t - 1 : 0, next_in);         // unconditional, clamped (see the forward kernel)
     float keep[2][4];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -368,11 +371,13 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
 
   GruStepIn<T> in_a, in_b;
   load_step(a.T - 1, in_a);
+  long t = a.T - 1;                               // reverse of the forward processing order
 #pragma unroll 1
-  for (long t = a.T - 1; t >= 0; t -= 2) {       // reverse of the forward processing order
+  for (; t >= 1; t -= 2) {
     step(t, in_a, in_b);
-    if (t - 1 >= 0) step(t - 1, in_b, in_a);
+    step(t - 1, in_b, in_a);
   }
+  if (t == 0) step(0, in_a, in_b);
 }
 
 template <typename T>

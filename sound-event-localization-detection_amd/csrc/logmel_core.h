@@ -12,7 +12,7 @@
 //     iteration produces 4 consecutive frames of one (clip, channel) row.
 //   * 960 = 32 x 30.  Stage A: lane n2 (<30) holds x[30*n1 + n2], n1 = 0..31, in registers
 //     and runs a straight-line 32-pt DFT (fft_gen.h), multiplies by W_960^{n2*k1}
-//     (register-resident twiddles) and writes column n2 of a [32][31] complex LDS tile.
+//     (two-level twiddles from the workgroup's LDS table) and writes column n2 of a [32][31] complex LDS tile.
 //     Because hop = 480 = 16*30, frame t+1's first half is frame t's second half IN THE SAME
 //     LANE, so a packed pair costs 48 coalesced dword loads per lane, not 64.
 //     Stage B: lane k1 reads row k1 (pitch 31 complex -> conflict free) and runs the
@@ -46,8 +46,6 @@ constexpr int kBsOff = kEFloats;                         // 3968: B_j hand-off, 
 constexpr int kLdsFloatsPerWave = kEFloats + 4 * 64;     // 4224 floats = 16896 B
 constexpr int kMelMaxCnt = 24;          // max bins owned by one lane (checked when tables are built)
 constexpr int kFramesPerIter = 4;
-constexpr int kItersPerGroup = 4;
-constexpr int kFramesPerGroup = kFramesPerIter * kItersPerGroup;   // 16
 constexpr float kAmin = 1e-10f;
 
 static_assert(kPOff + 4 * kPPitch + kMelMaxCnt <= kEFloats, "power rows (+over-read) must fit in the E tile");
@@ -61,14 +59,13 @@ struct LogmelTables {
   const float* mel_wu;    // [24][64]   fb[b0_j+i][j+1]
 };
 
-// Per-lane constants kept in registers for the whole kernel.
-struct LaneConst {
-  float win[kN1];
-  // two-level twiddles: W_960^{n2*k1} = hi[k1>>3] * lo[k1&7]  (10 complex registers, not 32)
-  float hir[4], hii[4];   // W^{n2*8a}, a = 0..3   (a = 0 is 1)
-  float lor[8], loi[8];   // W^{n2*b},  b = 0..7   (b = 0 is 1)
-  int b0;
-};
+// Workgroup-shared constant tables in LDS, stored lane-major in float4 quads so that every read is a
+// linear, conflict-free ds_read_b128 (lane l reads quad [q][l]).  Nothing constant lives in VGPRs:
+// the registers are spent on data (current samples, the next iteration's prefetched samples, the DFT).
+constexpr int kTabWin = 0;                         // [8][64][4]  Hann window w[30*n1 + n2], n1 = 4q+j
+constexpr int kTabTw = kTabWin + 8 * 64 * 4;       // [5][64][4]  10 complex: lo[1..7] = W^{n2*b}, hi[1..3] = W^{n2*8a}
+constexpr int kTabMel = kTabTw + 5 * 64 * 4;       // [12][64][4] (wd_i, wu_i, wd_{i+1}, wu_{i+1}), i = 2q
+constexpr int kTabFloats = kTabMel + 12 * 64 * 4;  // 6400 floats = 25600 B
 
 struct LaneAcc {
   float a[kFramesPerIter];
@@ -82,65 +79,89 @@ SELD_HD int p_index(int slot, int k) { return kPOff + slot * kPPitch + k; }
 SELD_HD float sample_to_float(float v) { return v; }
 SELD_HD float sample_to_float(int16_t v) { return static_cast<float>(v) * (1.0f / 32768.0f); }
 
-SELD_HD void load_lane_const(int lane, const LogmelTables& t, LaneConst& k) {
+// Value of flat element `e` of the LDS table block (used to fill it, on the GPU and in the emulator).
+SELD_HD float table_value(const LogmelTables& t, int e) {
+  const int lane = (e & 255) >> 2;
+  const int j = e & 3;
   const int l = lane & 31;
   const int n2 = l < kN2 ? l : kN2 - 1;
-#pragma unroll
-  for (int n1 = 0; n1 < kN1; ++n1) {
-    k.win[n1] = t.window[kN2 * n1 + n2];
+  if (e < kTabTw) {
+    const int n1 = 4 * (e >> 8) + j;
+    return t.window[kN2 * n1 + n2];
   }
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    k.hir[a] = t.twiddle[(n2 * kN1 + 8 * a) * 2 + 0];
-    k.hii[a] = t.twiddle[(n2 * kN1 + 8 * a) * 2 + 1];
+  if (e < kTabMel) {
+    const int ci = 2 * ((e - kTabTw) >> 8) + (j >> 1);         // 0..9
+    const int k1 = ci < 7 ? ci + 1 : 8 * (ci - 6);
+    return t.twiddle[(n2 * kN1 + k1) * 2 + (j & 1)];
   }
-#pragma unroll
-  for (int b = 0; b < 8; ++b) {
-    k.lor[b] = t.twiddle[(n2 * kN1 + b) * 2 + 0];
-    k.loi[b] = t.twiddle[(n2 * kN1 + b) * 2 + 1];
-  }
-  k.b0 = t.mel_b0[lane];
+  const int i = 2 * ((e - kTabMel) >> 8) + (j >> 1);
+  return (j & 1) ? t.mel_wu[i * 64 + lane] : t.mel_wd[i * 64 + lane];
 }
 
-// ---- Phase A: load 3 half-frames, window, pack two frames, 32-pt DFT, twiddle, LDS column store.
-// `fa` = index of the first (real-part) frame of this half-wavefront's pair.
+// ---- Sample fetch: the 48 samples x[480*(fa-1) + 30*m + n2], m = 0..47 of this lane (3 half-frames).
+// `fa` = index of the first (real-part) frame of this half-wavefront's pair.  kInterior: every index
+// is inside [0, L) -- no reflection, immediate-offset loads.
 template <typename T, bool kInterior>
-SELD_HD void phase_a(int lane, const T* row, long L, long fa, const LaneConst& k, float* lds) {
-  const int h = lane >> 5;
+SELD_HD void load_samples(int lane, const T* row, long L, long fa, float (&s)[48]) {
   const int l = lane & 31;
   const int n2 = l < kN2 ? l : kN2 - 1;
-  const long base = static_cast<long>(kHop) * (fa - 1) + n2;
-  float s[48];
+  if (kInterior) {
+    const T* p = row + static_cast<long>(kHop) * (fa - 1) + n2;
 #pragma unroll
-  for (int m = 0; m < 48; ++m) {
-    long idx = base + kN2 * m;
-    if (!kInterior) {
-      if (idx < 0) idx = -idx;                       // reflect (center=True, pad_mode='reflect')
-      if (idx >= L) idx = 2 * (L - 1) - idx;
-      idx = idx < 0 ? 0 : (idx >= L ? L - 1 : idx);  // frames past the end: any finite value
+    for (int m = 0; m < 48; ++m) s[m] = sample_to_float(p[kN2 * m]);
+  } else {
+    const int len = static_cast<int>(L);
+    const int base = kHop * (static_cast<int>(fa) - 1) + n2;
+#pragma unroll
+    for (int m = 0; m < 48; ++m) {
+      int idx = base + kN2 * m;
+      idx = idx < 0 ? -idx : idx;                            // reflect (center=True, pad_mode='reflect')
+      idx = idx >= len ? 2 * (len - 1) - idx : idx;
+      idx = idx < 0 ? 0 : (idx >= len ? len - 1 : idx);      // frames past the end: any finite value
+      s[m] = sample_to_float(row[idx]);
     }
-    s[m] = sample_to_float(row[idx]);
   }
+}
+
+// ---- Phase A: window, pack two frames, 32-pt DFT, twiddle, LDS column store.
+SELD_HD void phase_a(int lane, const float (&s)[48], const float* tab, float* lds) {
+  const int h = lane >> 5;
+  const int l = lane & 31;
   float re[kN1], im[kN1];
 #pragma unroll
-  for (int n1 = 0; n1 < kN1; ++n1) {
-    re[n1] = k.win[n1] * s[n1];            // frame fa
-    im[n1] = k.win[n1] * s[n1 + 16];       // frame fa+1 = same samples shifted by 480 = 16*30
+  for (int qd = 0; qd < 8; ++qd) {
+    const float* w = tab + kTabWin + (qd * 64 + lane) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n1 = 4 * qd + j;
+      re[n1] = w[j] * s[n1];            // frame fa
+      im[n1] = w[j] * s[n1 + 16];       // frame fa+1 = same samples shifted by 480 = 16*30
+    }
   }
   dft32(re, im);
+  // two-level twiddles W_960^{n2*k1} = hi[k1>>3] * lo[k1&7]
+  float tw[20];
+#pragma unroll
+  for (int v = 0; v < 5; ++v) {
+    const float* p = tab + kTabTw + (v * 64 + lane) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tw[4 * v + j] = p[j];
+  }
   if (l < kN2) {
 #pragma unroll
     for (int k1 = 0; k1 < kN1; ++k1) {
       const int a = k1 >> 3, b = k1 & 7;
       float yr = re[k1], yi = im[k1];
       if (b != 0) {
-        const float tr = yr * k.lor[b] - yi * k.loi[b];
-        yi = yr * k.loi[b] + yi * k.lor[b];
+        const float cr = tw[2 * (b - 1)], ci = tw[2 * (b - 1) + 1];
+        const float tr = yr * cr - yi * ci;
+        yi = yr * ci + yi * cr;
         yr = tr;
       }
       if (a != 0) {
-        const float tr = yr * k.hir[a] - yi * k.hii[a];
-        yi = yr * k.hii[a] + yi * k.hir[a];
+        const float cr = tw[2 * (6 + a)], ci = tw[2 * (6 + a) + 1];
+        const float tr = yr * cr - yi * ci;
+        yi = yr * ci + yi * cr;
         yr = tr;
       }
       const int o = e_index(h, k1, l);
@@ -211,20 +232,22 @@ SELD_HD void phase_c_store(int lane, float* lds, const float (&zr)[kN2], const f
 }
 
 // ---- Phase D: sparse mel.  Lane j accumulates over its own contiguous bins for all 4 frames.
-// The weights are streamed from the (L1/L2-resident, 12 KB) table every iteration rather than
-// pinned in 48 VGPRs: the kernel is tuned for 2 wavefronts per SIMD (256 VGPRs).
-SELD_HD void phase_d_accumulate(int lane, float* lds, const LogmelTables& t, const LaneConst& k, LaneAcc& acc) {
+// The filter weights come from the workgroup's LDS table (12 linear ds_read_b128 per iteration).
+SELD_HD void phase_d_accumulate(int lane, float* lds, const float* tab, int b0, LaneAcc& acc) {
 #pragma unroll
   for (int s = 0; s < kFramesPerIter; ++s) acc.a[s] = acc.b[s] = 0.0f;
 #pragma unroll
-  for (int i = 0; i < kMelMaxCnt; ++i) {
-    const float wd = t.mel_wd[i * 64 + lane];
-    const float wu = t.mel_wu[i * 64 + lane];
+  for (int ip = 0; ip < kMelMaxCnt / 2; ++ip) {
+    const float* w = tab + kTabMel + (ip * 64 + lane) * 4;
+    const float wd0 = w[0], wu0 = w[1], wd1 = w[2], wu1 = w[3];
 #pragma unroll
     for (int s = 0; s < kFramesPerIter; ++s) {
-      const float p = lds[p_index(s, k.b0 + i)];
-      acc.a[s] = fmaf(wd, p, acc.a[s]);
-      acc.b[s] = fmaf(wu, p, acc.b[s]);
+      const float p0 = lds[p_index(s, b0 + 2 * ip)];
+      const float p1 = lds[p_index(s, b0 + 2 * ip + 1)];
+      acc.a[s] = fmaf(wd0, p0, acc.a[s]);
+      acc.b[s] = fmaf(wu0, p0, acc.b[s]);
+      acc.a[s] = fmaf(wd1, p1, acc.a[s]);
+      acc.b[s] = fmaf(wu1, p1, acc.b[s]);
     }
   }
 #pragma unroll

@@ -153,13 +153,19 @@ __global__ __launch_bounds__(kLossBlock) void softmax_mse_kernel(const void* __r
   }
 }
 
-// Fixed-order final reduction -> mean squared error as float.
-__global__ void loss_finish_kernel(const double* __restrict__ partials, int n, double inv_count, float* __restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0;
-    for (int i = 0; i < n; ++i) s += partials[i];
-    out[0] = static_cast<float>(s * inv_count);
+// Fixed-order final reduction -> mean squared error as float (256 lanes, deterministic tree).
+__global__ __launch_bounds__(256) void loss_finish_kernel(const double* __restrict__ partials, int n, double inv_count,
+                                                          float* __restrict__ out) {
+  __shared__ double part[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (static_cast<int>(threadIdx.x) < off) part[threadIdx.x] += part[threadIdx.x + off];
+    __syncthreads();
   }
+  if (threadIdx.x == 0) out[0] = static_cast<float>(part[0] * inv_count);
 }
 
 template <bool kBf16, bool kMaskLabels, bool kGrad>
@@ -203,7 +209,7 @@ int seld_softmax_mse(const void* logits, int logits_is_bf16, const uint16_t* mas
   SELD_DISPATCH(true, true, false);   SELD_DISPATCH(true, true, true);
 #undef SELD_DISPATCH
   SELD_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, stream, partials, static_cast<int>(nb),
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, stream, partials, static_cast<int>(nb),
                      1.0 / (static_cast<double>(n_cells) * num_classes), loss_out);
   SELD_HIP_TRY(hipGetLastError());
   return kOk;

@@ -37,53 +37,54 @@ int run(const T* pcm, int64_t N, int64_t C, int64_t L, float* out, int layout, c
   const LogmelTables tab = t.view();
 
   const long F = 1 + L / kHop;
-  const long groups = (F + kFramesPerGroup - 1) / kFramesPerGroup;
   long sN, sC, sM, sT;
   if (layout == 0) { sT = 1; sM = F; sC = kMels * F; sN = C * kMels * F; }
   else { sM = 1; sC = kMels; sT = C * kMels; sN = F * C * kMels; }
 
   std::vector<float> lds(kLdsFloatsPerWave, 0.0f);
-  std::vector<LaneConst> k(64);
-  for (int lane = 0; lane < 64; ++lane) load_lane_const(lane, tab, k[lane]);
+  std::vector<float> tab_lds(kTabFloats);
+  for (int e = 0; e < kTabFloats; ++e) tab_lds[e] = table_value(tab, e);
   std::vector<float> zr(64 * kN2), zi(64 * kN2), mr(64 * 16), mi(64 * 16);
+  std::vector<float> smp(64 * 48);
   std::vector<LaneAcc> acc(64);
+  const long iters_per_row = (F + kFramesPerIter - 1) / kFramesPerIter;
 
   for (long row = 0; row < N * C; ++row) {
     const T* rowp = pcm + row * L;
     const long n = row / C, c = row % C;
-    for (long g = 0; g < groups; ++g) {
-      const long t0 = g * kFramesPerGroup;
-      const bool interior = (t0 >= 1) && (static_cast<long>(kHop) * (t0 + kFramesPerGroup) <= L);
-      for (int it = 0; it < kItersPerGroup; ++it) {
-        const long tf = t0 + it * kFramesPerIter;
-        if (tf >= F) break;
-        for (int lane = 0; lane < 64; ++lane) {
-          const long fa = tf + 2 * (lane >> 5);
-          if (interior) phase_a<T, true>(lane, rowp, L, fa, k[lane], lds.data());
-          else phase_a<T, false>(lane, rowp, L, fa, k[lane], lds.data());
-        }
-        for (int lane = 0; lane < 64; ++lane)
-          phase_b(lane, lds.data(), *reinterpret_cast<float(*)[kN2]>(&zr[lane * kN2]),
-                  *reinterpret_cast<float(*)[kN2]>(&zi[lane * kN2]));
-        for (int lane = 0; lane < 64; ++lane)
-          phase_b_store(lane, lds.data(), *reinterpret_cast<float(*)[kN2]>(&zr[lane * kN2]),
-                        *reinterpret_cast<float(*)[kN2]>(&zi[lane * kN2]));
-        for (int lane = 0; lane < 64; ++lane)
-          phase_c_load(lane, lds.data(), *reinterpret_cast<float(*)[16]>(&mr[lane * 16]),
-                       *reinterpret_cast<float(*)[16]>(&mi[lane * 16]));
-        for (int lane = 0; lane < 64; ++lane)
-          phase_c_store(lane, lds.data(), *reinterpret_cast<float(*)[kN2]>(&zr[lane * kN2]),
-                        *reinterpret_cast<float(*)[kN2]>(&zi[lane * kN2]),
-                        *reinterpret_cast<float(*)[16]>(&mr[lane * 16]),
-                        *reinterpret_cast<float(*)[16]>(&mi[lane * 16]));
-        for (int lane = 0; lane < 64; ++lane) phase_d_accumulate(lane, lds.data(), tab, k[lane], acc[lane]);
-        for (int lane = 0; lane < 64; ++lane) {
-          float db[kFramesPerIter];
-          phase_d_finish(lane, lds.data(), acc[lane], db);
-          float* outp = out + n * sN + c * sC + lane * sM;
-          for (int s = 0; s < kFramesPerIter; ++s)
-            if (tf + s < F) outp[(tf + s) * sT] = db[s];
-        }
+    for (long itr = 0; itr < iters_per_row; ++itr) {
+      const long tf = itr * kFramesPerIter;
+      const bool interior = (tf >= 1) && (static_cast<long>(kHop) * (tf + kFramesPerIter) <= L);
+      for (int lane = 0; lane < 64; ++lane) {
+        const long fa = tf + 2 * (lane >> 5);
+        float(&s)[48] = *reinterpret_cast<float(*)[48]>(&smp[lane * 48]);
+        if (interior) load_samples<T, true>(lane, rowp, L, fa, s);
+        else load_samples<T, false>(lane, rowp, L, fa, s);
+      }
+      for (int lane = 0; lane < 64; ++lane)
+        phase_a(lane, *reinterpret_cast<float(*)[48]>(&smp[lane * 48]), tab_lds.data(), lds.data());
+      for (int lane = 0; lane < 64; ++lane)
+        phase_b(lane, lds.data(), *reinterpret_cast<float(*)[kN2]>(&zr[lane * kN2]),
+                *reinterpret_cast<float(*)[kN2]>(&zi[lane * kN2]));
+      for (int lane = 0; lane < 64; ++lane)
+        phase_b_store(lane, lds.data(), *reinterpret_cast<float(*)[kN2]>(&zr[lane * kN2]),
+                      *reinterpret_cast<float(*)[kN2]>(&zi[lane * kN2]));
+      for (int lane = 0; lane < 64; ++lane)
+        phase_c_load(lane, lds.data(), *reinterpret_cast<float(*)[16]>(&mr[lane * 16]),
+                     *reinterpret_cast<float(*)[16]>(&mi[lane * 16]));
+      for (int lane = 0; lane < 64; ++lane)
+        phase_c_store(lane, lds.data(), *reinterpret_cast<float(*)[kN2]>(&zr[lane * kN2]),
+                      *reinterpret_cast<float(*)[kN2]>(&zi[lane * kN2]),
+                      *reinterpret_cast<float(*)[16]>(&mr[lane * 16]),
+                      *reinterpret_cast<float(*)[16]>(&mi[lane * 16]));
+      for (int lane = 0; lane < 64; ++lane)
+        phase_d_accumulate(lane, lds.data(), tab_lds.data(), t.b0[lane], acc[lane]);
+      for (int lane = 0; lane < 64; ++lane) {
+        float db[kFramesPerIter];
+        phase_d_finish(lane, lds.data(), acc[lane], db);
+        float* outp = out + n * sN + c * sC + lane * sM;
+        for (int s = 0; s < kFramesPerIter; ++s)
+          if (tf + s < F) outp[(tf + s) * sT] = db[s];
       }
     }
   }
