@@ -4,148 +4,153 @@
 
 namespace seld {
 
-constexpr int kWavesPerWg = 4;                       // one wavefront per SIMD: 512 VGPRs each, nothing ever spills
-constexpr int kLogmelLdsBytes = (kTabFloats + kWavesPerWg * kLdsFloatsPerWave) * 4;   // 93184 B (one WG per CU)
+constexpr int kMainWaves = 8;    // main kernel: 512 threads, two wavefronts per SIMD (<= 256 VGPRs, no spills)
+constexpr int kEdgeWaves = 4;    // edge kernel: 256 threads
+constexpr int kMainLdsBytes = (kTabFloats + kMainWaves * kLdsFloatsPerWave) * 4;   // 160768 B: one workgroup per CU
+constexpr int kEdgeLdsBytes = (kTabFloats + kEdgeWaves * kLdsFloatsPerWave) * 4;
 
 struct LogmelArgs {
   const void* pcm;      // [rows][L], rows = N*C
   float* out;
   long rows, C, L, F;   // F = 1 + L/480 frames
   long iters_per_row;   // ceil(F / 4): one iteration = 4 consecutive frames of one row
-  long total_iters;     // rows * iters_per_row
-  long chunk;           // consecutive iterations per wavefront
+  long interior;        // iterations 1..interior of every row touch only samples inside [0, L) and store 4 frames
+  long edge_per_row;    // the others (first / last of a row): iters_per_row - interior
+  long chunk;           // consecutive interior iterations per wavefront (main kernel)
   long sN, sC, sM, sT;  // output strides (elements): clip, channel, mel band, frame
   LogmelTables tab;
 };
 
-struct IterCtx {
-  long L, F, C;
-  long sN, sC, sM, sT;
-  long row, itr;        // this iteration: (clip*C + channel), 4-frame index inside the row
-  long nrow, nitr;      // the next one (prefetch target)
-  bool have_next;
-};
-
-__device__ __forceinline__ bool iter_is_interior(long it_in_row, long L) {
-  // every 48-sample column of both half-wavefronts inside [0, L): no reflection, no clamping
-  const long tf = it_in_row * kFramesPerIter;
-  return (tf >= 1) && (static_cast<long>(kHop) * (tf + kFramesPerIter) <= L);
+__device__ __forceinline__ float* out_pointer(const LogmelArgs& a, long row, long itr, int lane) {
+  const long n = row / a.C;
+  const long c = row - n * a.C;
+  return a.out + n * a.sN + c * a.sC + lane * a.sM + itr * kFramesPerIter * a.sT;
 }
 
-// One iteration = 4 frames of one row.  The samples of the NEXT iteration are requested at the top of this
-// one and consumed at the top of the next, so a wavefront never waits on HBM.  The kernel runs ONE wavefront
-// per SIMD (512 VGPRs): current samples, prefetched samples, DFT data and temporaries all stay in registers.
-// kFast: the next iteration exists and is interior and THIS one stores all 4 frames: no divergent or
-// conditional memory operation, so the compiler counts outstanding loads / stores exactly (no vmcnt(0)).
-// Edge iterations (first / last of a row, last of the run) take the generic body, which ends with an
-// explicit drain so both paths meet at the loop head in a known state.
-template <typename T, bool kFast>
-__device__ __forceinline__ void logmel_iteration(const IterCtx& x, const T* pcm, float* out, const float* tab,
-                                                 float* lds, int lane, int b0, float (&s_cur)[48], float (&s_next)[48]) {
-  const int h = lane >> 5;
-  const long tf = x.itr * kFramesPerIter;
-  const long n = x.row / x.C;
-  const long c = x.row - n * x.C;
-  float* outp = out + n * x.sN + c * x.sC + lane * x.sM + tf * x.sT;
-
-  // ---- prefetch the next iteration's samples first: a whole iteration of cover for their HBM latency
-  if (kFast) {
-    load_samples<T, true>(lane, pcm + x.nrow * x.L, x.L, x.nitr * kFramesPerIter + 2 * h, s_next);
-  } else if (x.have_next) {
-    const T* rowp = pcm + x.nrow * x.L;
-    const long fa = x.nitr * kFramesPerIter + 2 * h;
-    if (iter_is_interior(x.nitr, x.L)) load_samples<T, true>(lane, rowp, x.L, fa, s_next);
-    else load_samples<T, false>(lane, rowp, x.L, fa, s_next);
-  }
-
-  phase_a(lane, s_cur, tab, lds);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-
-  float zr[kN2], zi[kN2];
-  phase_b(lane, lds, zr, zi);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  phase_b_store(lane, lds, zr, zi);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-
-  float mr[16], mi[16];
-  phase_c_load(lane, lds, mr, mi);
-  phase_c_store(lane, lds, zr, zi, mr, mi);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-
-  LaneAcc acc;
-  phase_d_accumulate(lane, lds, tab, b0, acc);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  float db[kFramesPerIter];
-  phase_d_finish(lane, lds, acc, db);
-  if (kFast) {
-#pragma unroll
-    for (int s = 0; s < kFramesPerIter; ++s) outp[s * x.sT] = db[s];
-  } else {
-#pragma unroll
-    for (int s = 0; s < kFramesPerIter; ++s)
-      if (tf + s < x.F) outp[s * x.sT] = db[s];
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  if (!kFast) __builtin_amdgcn_s_waitcnt(0);         // vmcnt(0) lgkmcnt(0): known state at the join
-#pragma unroll
-  for (int m = 0; m < 48; ++m) s_cur[m] = s_next[m];
+__device__ __forceinline__ void fill_tables(const LogmelArgs& a, float* tab, int tid, int nthreads) {
+  for (int e = tid; e < kTabFloats; e += nthreads) tab[e] = table_value(a.tab, e);
 }
 
+#define SELD_WAVE_SYNC()                                   \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
+  } while (0)
+
+// ---- Main kernel: the interior iterations of every row (all but the first and the last one or two).
 // One wavefront = one independent pipeline over a contiguous run of iterations; the 8 wavefronts of a
-// workgroup only share the read-only LDS tables (one barrier, at start-up).
+// workgroup only share the read-only LDS tables (one barrier, at start-up).  The body has NO divergent or
+// conditional memory operation: the compiler counts the outstanding prefetch loads / output stores exactly,
+// so nothing ever drains the memory queue (no vmcnt(0)), and the samples of the next iteration are requested
+// right after stage B -- into the registers the window multiply has just freed -- so their HBM latency is
+// covered by the un-packing / mel / store phases and by the SIMD's other wavefront.
 template <typename T>
-__global__ __launch_bounds__(kWavesPerWg * 64, 1) void logmel_kernel(LogmelArgs a) {
+__global__ __launch_bounds__(kMainWaves * 64, 2) void logmel_main_kernel(LogmelArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
+  const int h = lane >> 5;
   float* tab = smem;
   float* lds = smem + kTabFloats + wave * kLdsFloatsPerWave;
-
-  for (int e = tid; e < kTabFloats; e += kWavesPerWg * 64) tab[e] = table_value(a.tab, e);
+  fill_tables(a, tab, tid, kMainWaves * 64);
   // Zero the wavefront's tile once: pad cells are otherwise never written and the mel phase multiplies
   // over-read cells by a zero weight (0 * NaN would poison the sum).
   for (int i = lane; i < kLdsFloatsPerWave; i += 64) lds[i] = 0.0f;
   const int b0 = a.tab.mel_b0[lane];
   __syncthreads();
 
-  const long gw = static_cast<long>(blockIdx.x) * kWavesPerWg + wave;
+  const long total = a.rows * a.interior;
+  const long gw = static_cast<long>(blockIdx.x) * kMainWaves + wave;
   const long begin = gw * a.chunk;
-  const long end = begin + a.chunk < a.total_iters ? begin + a.chunk : a.total_iters;
+  const long end = begin + a.chunk < total ? begin + a.chunk : total;
   if (begin >= end) return;
   const T* pcm = static_cast<const T*>(a.pcm);
 
-  IterCtx x;
-  x.L = a.L; x.F = a.F; x.C = a.C;
-  x.sN = a.sN; x.sC = a.sC; x.sM = a.sM; x.sT = a.sT;
-  x.row = begin / a.iters_per_row;
-  x.itr = begin - x.row * a.iters_per_row;
-
-  float s_cur[48], s_next[48];
-  {
-    const T* rowp = pcm + x.row * a.L;
-    const long fa = x.itr * kFramesPerIter + 2 * (lane >> 5);
-    if (iter_is_interior(x.itr, a.L)) load_samples<T, true>(lane, rowp, a.L, fa, s_cur);
-    else load_samples<T, false>(lane, rowp, a.L, fa, s_cur);
-  }
+  long row = begin / a.interior;
+  long itr = 1 + (begin - row * a.interior);
+  float s[48];
+  load_samples<T, true>(lane, pcm + row * a.L, a.L, itr * kFramesPerIter + 2 * h, s);
 
 #pragma unroll 1
   for (long it = begin; it < end; ++it) {
-    x.nrow = x.row;
-    x.nitr = x.itr + 1;
-    if (x.nitr == a.iters_per_row) { x.nitr = 0; ++x.nrow; }
-    x.have_next = it + 1 < end;
-    const bool fast = x.have_next && iter_is_interior(x.nitr, a.L) && (x.itr * kFramesPerIter + kFramesPerIter <= a.F);
-    if (fast) logmel_iteration<T, true>(x, pcm, a.out, tab, lds, lane, b0, s_cur, s_next);
-    else logmel_iteration<T, false>(x, pcm, a.out, tab, lds, lane, b0, s_cur, s_next);
-    x.row = x.nrow;
-    x.itr = x.nitr;
+    long nrow = row, nitr = itr;
+    if (it + 1 < end) {                       // scalar bookkeeping only; the fetch below is unconditional
+      ++nitr;
+      if (nitr > a.interior) { nitr = 1; ++nrow; }
+    }
+    float* outp = out_pointer(a, row, itr, lane);
+
+    phase_a(lane, s, tab, lds);
+    SELD_WAVE_SYNC();
+    float zr[kN2], zi[kN2];
+    phase_b(lane, lds, zr, zi);
+    SELD_WAVE_SYNC();
+    phase_b_store(lane, lds, zr, zi);
+    SELD_WAVE_SYNC();
+    load_samples<T, true>(lane, pcm + nrow * a.L, a.L, nitr * kFramesPerIter + 2 * h, s);   // prefetch
+    float mr[16], mi[16];
+    phase_c_load(lane, lds, mr, mi);
+    phase_c_store(lane, lds, zr, zi, mr, mi);
+    SELD_WAVE_SYNC();
+    LaneAcc acc;
+    phase_d_accumulate(lane, lds, tab, b0, acc);
+    SELD_WAVE_SYNC();
+    float db[kFramesPerIter];
+    phase_d_finish(lane, lds, acc, db);
+#pragma unroll
+    for (int f = 0; f < kFramesPerIter; ++f) outp[f * a.sT] = db[f];
+    SELD_WAVE_SYNC();
+    row = nrow;
+    itr = nitr;
   }
+}
+
+// ---- Edge kernel: the first iteration of every row (reflection on the left) and the last one or two
+// (reflection on the right, frames past the end masked).  One wavefront per edge iteration, no pipelining:
+// rows * edge_per_row iterations in total (256 for 32 one-minute clips) against ~96 000 interior ones.
+template <typename T>
+__global__ __launch_bounds__(kEdgeWaves * 64, 1) void logmel_edge_kernel(LogmelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int h = lane >> 5;
+  float* tab = smem;
+  float* lds = smem + kTabFloats + wave * kLdsFloatsPerWave;
+  fill_tables(a, tab, tid, kEdgeWaves * 64);
+  for (int i = lane; i < kLdsFloatsPerWave; i += 64) lds[i] = 0.0f;
+  const int b0 = a.tab.mel_b0[lane];
+  __syncthreads();
+
+  const long e = static_cast<long>(blockIdx.x) * kEdgeWaves + wave;
+  if (e >= a.rows * a.edge_per_row) return;
+  const long row = e / a.edge_per_row;
+  const long j = e - row * a.edge_per_row;
+  const long itr = a.interior >= 1 ? (j == 0 ? 0 : a.interior + j) : j;
+  const long tf = itr * kFramesPerIter;
+  const T* pcm = static_cast<const T*>(a.pcm);
+
+  float s[48];
+  load_samples<T, false>(lane, pcm + row * a.L, a.L, tf + 2 * h, s);
+  phase_a(lane, s, tab, lds);
+  SELD_WAVE_SYNC();
+  float zr[kN2], zi[kN2];
+  phase_b(lane, lds, zr, zi);
+  SELD_WAVE_SYNC();
+  phase_b_store(lane, lds, zr, zi);
+  SELD_WAVE_SYNC();
+  float mr[16], mi[16];
+  phase_c_load(lane, lds, mr, mi);
+  phase_c_store(lane, lds, zr, zi, mr, mi);
+  SELD_WAVE_SYNC();
+  LaneAcc acc;
+  phase_d_accumulate(lane, lds, tab, b0, acc);
+  SELD_WAVE_SYNC();
+  float db[kFramesPerIter];
+  phase_d_finish(lane, lds, acc, db);
+  float* outp = out_pointer(a, row, itr, lane);
+#pragma unroll
+  for (int f = 0; f < kFramesPerIter; ++f)
+    if (tf + f < a.F) outp[f * a.sT] = db[f];
 }
 
 template <typename T>
@@ -168,7 +173,11 @@ static int launch_logmel(const T* pcm, int64_t N, int64_t C, int64_t L, float* o
   a.L = L;
   a.F = 1 + L / kHop;
   a.iters_per_row = (a.F + kFramesPerIter - 1) / kFramesPerIter;
-  a.total_iters = a.rows * a.iters_per_row;
+  // iteration i (frames 4i..4i+3) is interior iff i >= 1 and 480*(4i+4) <= L
+  a.interior = (L / kHop - kFramesPerIter) / kFramesPerIter;
+  if (a.interior < 0) a.interior = 0;
+  if (a.interior > a.iters_per_row - 1) a.interior = a.iters_per_row - 1;
+  a.edge_per_row = a.iters_per_row - a.interior;
   if (layout == 0) {            // [N, C, 64, F]  (reference layout, dataset.py:53)
     a.sT = 1;
     a.sM = a.F;
@@ -181,23 +190,34 @@ static int launch_logmel(const T* pcm, int64_t N, int64_t C, int64_t L, float* o
     a.sN = a.F * C * kMels;
   }
   a.tab = st->tables();
-  // one 4-wavefront workgroup per CU (one wavefront per SIMD); every wavefront gets a contiguous run of >= 16 iterations
-  const long max_waves = static_cast<long>(st->num_cus) * kWavesPerWg;
-  long waves = (a.total_iters + 15) / 16;
-  if (waves > max_waves) waves = max_waves;
-  a.chunk = (a.total_iters + waves - 1) / waves;
-  const long used_waves = (a.total_iters + a.chunk - 1) / a.chunk;
-  const long grid = (used_waves + kWavesPerWg - 1) / kWavesPerWg;
+  a.chunk = 1;
+
   static bool attr_done[2] = {false, false};
   const int which = sizeof(T) == 4 ? 0 : 1;
   if (!attr_done[which]) {
-    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<T>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLogmelLdsBytes));
+    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_main_kernel<T>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kMainLdsBytes));
+    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_edge_kernel<T>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kEdgeLdsBytes));
     attr_done[which] = true;
   }
-  hipLaunchKernelGGL(logmel_kernel<T>, dim3(static_cast<unsigned>(grid)), dim3(kWavesPerWg * 64), kLogmelLdsBytes,
-                     stream, a);
+  const long n_edge = a.rows * a.edge_per_row;
+  hipLaunchKernelGGL(logmel_edge_kernel<T>, dim3(static_cast<unsigned>((n_edge + kEdgeWaves - 1) / kEdgeWaves)),
+                     dim3(kEdgeWaves * 64), kEdgeLdsBytes, stream, a);
   SELD_HIP_TRY(hipGetLastError());
+  const long total = a.rows * a.interior;
+  if (total > 0) {
+    // one 8-wavefront workgroup per CU (LDS bound); every wavefront gets a contiguous run of >= 16 iterations
+    const long max_waves = static_cast<long>(st->num_cus) * kMainWaves;
+    long waves = (total + 15) / 16;
+    if (waves > max_waves) waves = max_waves;
+    a.chunk = (total + waves - 1) / waves;
+    const long used_waves = (total + a.chunk - 1) / a.chunk;
+    const long grid = (used_waves + kMainWaves - 1) / kMainWaves;
+    hipLaunchKernelGGL(logmel_main_kernel<T>, dim3(static_cast<unsigned>(grid)), dim3(kMainWaves * 64), kMainLdsBytes,
+                       stream, a);
+    SELD_HIP_TRY(hipGetLastError());
+  }
   return kOk;
 }
 

@@ -87,7 +87,8 @@ SELD_HD float table_value(const LogmelTables& t, int e) {
   const int n2 = l < kN2 ? l : kN2 - 1;
   if (e < kTabTw) {
     const int n1 = 4 * (e >> 8) + j;
-    return t.window[kN2 * n1 + n2];
+    // half the window: the packed transform then yields X/2, so |Xa|^2 = ar^2 + ai^2 needs no 1/4
+    return 0.5f * t.window[kN2 * n1 + n2];
   }
   if (e < kTabMel) {
     const int ci = 2 * ((e - kTabTw) >> 8) + (j >> 1);         // 0..9
@@ -123,31 +124,36 @@ SELD_HD void load_samples(int lane, const T* row, long L, long fa, float (&s)[48
   }
 }
 
+// NOTE on addressing: every LDS access below is written as  (one per-lane base pointer)[compile-time
+// constant]  so that it becomes a single base VGPR plus the DS instruction's immediate offset.  Spelling
+// the index as one expression makes the compiler hoist a separate loop-invariant address register for
+// every distinct constant (dozens of VGPRs, which then spill).
+
 // ---- Phase A: window, pack two frames, 32-pt DFT, twiddle, LDS column store.
 SELD_HD void phase_a(int lane, const float (&s)[48], const float* tab, float* lds) {
   const int h = lane >> 5;
   const int l = lane & 31;
+  const float* tl = tab + lane * 4;                    // this lane's quad in every table row
   float re[kN1], im[kN1];
 #pragma unroll
   for (int qd = 0; qd < 8; ++qd) {
-    const float* w = tab + kTabWin + (qd * 64 + lane) * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n1 = 4 * qd + j;
-      re[n1] = w[j] * s[n1];            // frame fa
-      im[n1] = w[j] * s[n1 + 16];       // frame fa+1 = same samples shifted by 480 = 16*30
+      const float w = tl[kTabWin + qd * 256 + j];        // 0.5 * Hann (see table_value)
+      re[n1] = w * s[n1];            // frame fa
+      im[n1] = w * s[n1 + 16];       // frame fa+1 = same samples shifted by 480 = 16*30
     }
   }
   dft32(re, im);
   // two-level twiddles W_960^{n2*k1} = hi[k1>>3] * lo[k1&7]
   float tw[20];
 #pragma unroll
-  for (int v = 0; v < 5; ++v) {
-    const float* p = tab + kTabTw + (v * 64 + lane) * 4;
+  for (int v = 0; v < 5; ++v)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) tw[4 * v + j] = p[j];
-  }
+    for (int j = 0; j < 4; ++j) tw[4 * v + j] = tl[kTabTw + v * 256 + j];
   if (l < kN2) {
+    float* e = lds + e_index(h, 0, l);                 // column l of this half's tile; row k1 is at +62*k1
 #pragma unroll
     for (int k1 = 0; k1 < kN1; ++k1) {
       const int a = k1 >> 3, b = k1 & 7;
@@ -164,9 +170,8 @@ SELD_HD void phase_a(int lane, const float (&s)[48], const float* tab, float* ld
         yi = yr * ci + yi * cr;
         yr = tr;
       }
-      const int o = e_index(h, k1, l);
-      lds[o] = yr;
-      lds[o + 1] = yi;
+      e[k1 * kEPitch * 2] = yr;
+      e[k1 * kEPitch * 2 + 1] = yi;
     }
   }
 }
@@ -175,11 +180,11 @@ SELD_HD void phase_a(int lane, const float (&s)[48], const float* tab, float* ld
 SELD_HD void phase_b(int lane, float* lds, float (&zr)[kN2], float (&zi)[kN2]) {
   const int h = lane >> 5;
   const int l = lane & 31;
+  const float* e = lds + e_index(h, l, 0);             // row l
 #pragma unroll
   for (int n2 = 0; n2 < kN2; ++n2) {
-    const int o = e_index(h, l, n2);
-    zr[n2] = lds[o];
-    zi[n2] = lds[o + 1];
+    zr[n2] = e[2 * n2];
+    zi[n2] = e[2 * n2 + 1];
   }
   dft30(zr, zi);   // zr/zi[k2] = Z[l + 32*k2]
 }
@@ -187,46 +192,47 @@ SELD_HD void phase_b(int lane, float* lds, float (&zr)[kN2], float (&zi)[kN2]) {
 SELD_HD void phase_b_store(int lane, float* lds, const float (&zr)[kN2], const float (&zi)[kN2]) {
   const int h = lane >> 5;
   const int l = lane & 31;
+  float* z = lds + zm_index(h, l);                     // entry (l + 32*k2 - 480) is at +64*(k2-15)
 #pragma unroll
   for (int k2 = 15; k2 < kN2; ++k2) {
-    const int o = zm_index(h, l + 32 * k2 - 480);
-    lds[o] = zr[k2];
-    lds[o + 1] = zi[k2];
+    z[64 * (k2 - 15)] = zr[k2];
+    z[64 * (k2 - 15) + 1] = zi[k2];
   }
   if (l == 0) {   // Z[960] == Z[0]
-    const int o = zm_index(h, 480);
-    lds[o] = zr[0];
-    lds[o + 1] = zi[0];
+    z[960] = zr[0];
+    z[961] = zi[0];
   }
 }
 
 // ---- Phase C: un-pack the two real spectra and write |X|^2 for bins 0..480 of both frames.
-//   Xa[k] = (Z[k] + conj Z[N-k]) / 2 ,  Xb[k] = (Z[k] - conj Z[N-k]) / (2i)
+//   Xa[k] = (Z[k] + conj Z[N-k]) / 2 ,  Xb[k] = (Z[k] - conj Z[N-k]) / (2i); the 1/2 is in the window table
 SELD_HD void phase_c_load(int lane, const float* lds, float (&mr)[16], float (&mi)[16]) {
   const int h = lane >> 5;
   const int l = lane & 31;
+  // mirror entry 480 - (l + 32 r) = (0 - l) + 32*(15 - r): base at r = 15 (entry -l), ascending by 64 floats
+  const float* m = lds + zm_index(h, 0) - 2 * l;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int k = l + 32 * r;
-    const int idx = (r < 15 || l == 0) ? 480 - k : 0;
-    const int o = zm_index(h, idx);
-    mr[r] = lds[o];
-    mi[r] = lds[o + 1];
+  for (int r = 0; r < 15; ++r) {
+    mr[r] = m[64 * (15 - r)];
+    mi[r] = m[64 * (15 - r) + 1];
   }
+  const float* m0 = lds + zm_index(h, 0);              // r = 15: bin 480 (lane 0 only; others read a dummy)
+  mr[15] = m0[0];
+  mi[15] = m0[1];
 }
 
 SELD_HD void phase_c_store(int lane, float* lds, const float (&zr)[kN2], const float (&zi)[kN2],
-                                  const float (&mr)[16], const float (&mi)[16]) {
+                           const float (&mr)[16], const float (&mi)[16]) {
   const int h = lane >> 5;
   const int l = lane & 31;
+  float* p = lds + p_index(2 * h, l);                  // bin l + 32 r of frame slot 2h is at +32 r, slot 2h+1 at +484
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     if (r < 15 || l == 0) {
-      const int k = l + 32 * r;
       const float ar = zr[r] + mr[r], ai = zi[r] - mi[r];
       const float br = zi[r] + mi[r], bi = zr[r] - mr[r];
-      lds[p_index(2 * h, k)] = 0.25f * (ar * ar + ai * ai);
-      lds[p_index(2 * h + 1, k)] = 0.25f * (br * br + bi * bi);
+      p[32 * r] = ar * ar + ai * ai;
+      p[kPPitch + 32 * r] = br * br + bi * bi;
     }
   }
 }
@@ -234,34 +240,43 @@ SELD_HD void phase_c_store(int lane, float* lds, const float (&zr)[kN2], const f
 // ---- Phase D: sparse mel.  Lane j accumulates over its own contiguous bins for all 4 frames.
 // The filter weights come from the workgroup's LDS table (12 linear ds_read_b128 per iteration).
 SELD_HD void phase_d_accumulate(int lane, float* lds, const float* tab, int b0, LaneAcc& acc) {
+  const float* tl = tab + kTabMel + lane * 4;
+  const float* p = lds + kPOff + b0;                   // power rows: slot s at +484 s
 #pragma unroll
   for (int s = 0; s < kFramesPerIter; ++s) acc.a[s] = acc.b[s] = 0.0f;
 #pragma unroll
   for (int ip = 0; ip < kMelMaxCnt / 2; ++ip) {
-    const float* w = tab + kTabMel + (ip * 64 + lane) * 4;
-    const float wd0 = w[0], wu0 = w[1], wd1 = w[2], wu1 = w[3];
+    const float wd0 = tl[ip * 256 + 0], wu0 = tl[ip * 256 + 1], wd1 = tl[ip * 256 + 2], wu1 = tl[ip * 256 + 3];
 #pragma unroll
     for (int s = 0; s < kFramesPerIter; ++s) {
-      const float p0 = lds[p_index(s, b0 + 2 * ip)];
-      const float p1 = lds[p_index(s, b0 + 2 * ip + 1)];
+      const float p0 = p[s * kPPitch + 2 * ip];
+      const float p1 = p[s * kPPitch + 2 * ip + 1];
       acc.a[s] = fmaf(wd0, p0, acc.a[s]);
       acc.b[s] = fmaf(wu0, p0, acc.b[s]);
       acc.a[s] = fmaf(wd1, p1, acc.a[s]);
       acc.b[s] = fmaf(wu1, p1, acc.b[s]);
     }
   }
+  float* bs = lds + kBsOff + lane;
 #pragma unroll
-  for (int s = 0; s < kFramesPerIter; ++s) lds[kBsOff + s * 64 + lane] = acc.b[s];
+  for (int s = 0; s < kFramesPerIter; ++s) bs[s * 64] = acc.b[s];
 }
 
-// 10*log10(max(p, 1e-10)); the floor is returned as exactly -100 dB (what the CPU path yields),
-// independent of the last-ulp behaviour of the device log10f.
-SELD_HD float power_to_db(float p) { return p > kAmin ? 10.0f * log10f(p) : -100.0f; }
+// 10*log10(max(p, 1e-10)) as 10*log10(2) * log2(p): one v_log_f32 (<= 1 ulp of log2, i.e. < 1e-5 dB) instead
+// of the ~15-instruction log10f.  The floor is returned as exactly -100 dB (what the CPU path yields).
+SELD_HD float power_to_db(float p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float l2 = __log2f(p);
+#else
+  const float l2 = log2f(p);
+#endif
+  return p > kAmin ? 3.0102999566398120f * l2 : -100.0f;
+}
 
 SELD_HD void phase_d_finish(int lane, const float* lds, const LaneAcc& acc, float (&db)[kFramesPerIter]) {
 #pragma unroll
   for (int s = 0; s < kFramesPerIter; ++s) {
-    const float below = lane > 0 ? lds[kBsOff + s * 64 + lane - 1] : 0.0f;
+    const float below = lane > 0 ? (lds + kBsOff + lane - 1)[s * 64] : 0.0f;
     db[s] = power_to_db(acc.a[s] + below);
   }
 }
