@@ -93,12 +93,14 @@ int seld_softmax_mse(const void* logits, int logits_is_bf16, const uint16_t* mas
 /* ---- recurrence: nn.GRU(2048, 256, num_layers=2, bidirectional) at model_crnn.py:65-72 ------- */
 /* One bidirectional GRU layer's recurrence, all T steps in one launch (both directions).
  *   gi      [B][T][2][3H]  input projections x W_ih^T + b_ih, gate order r|z|n, direction 0 = forward in
- *                          time, 1 = reverse (fp32, or bf16 when is_bf16)
- *   w_hh    [2][3H][H] bf16,  b_hh [2][3H] fp32,  h0 = 0
+ *                          time, 1 = reverse (fp32, or bf16 when is_bf16).  The recurrent biases of the r and
+ *                          z gates (b_hh[0:2H]) must ALREADY be added into gi (they commute with the sigmoid
+ *                          argument); only the n-gate bias stays separate because it sits inside r * (.)
+ *   w_hh    [2][3H][H] bf16,  b_hn [2][H] fp32 (= b_hh[2H:3H] per direction),  h0 = 0
  *   y       [B][T][2H]     h_t, forward direction in [..., :H], reverse in [..., H:] (dtype of gi)
  *   saved   [B][T][2][4][H] fp32: r, z, n, (W_hn h + b_hn) per step for the backward pass, or NULL
  * H must be 256.  MFMA bf16 inputs, fp32 accumulation, fp32 gates and state. */
-int seld_gru_forward(const void* gi, int is_bf16, const void* w_hh_bf16, const float* b_hh, int64_t B, int64_t T,
+int seld_gru_forward(const void* gi, int is_bf16, const void* w_hh_bf16, const float* b_hn, int64_t B, int64_t T,
                      int64_t H, void* y, float* saved, void* stream);
 
 /* Backward of the recurrence.  dy [B][T][2H] (dtype of y), w_hh_t [2][H][3H] bf16 (W_hh transposed).

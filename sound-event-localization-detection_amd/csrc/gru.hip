@@ -47,11 +47,8 @@ template <> __device__ __forceinline__ __hip_bfloat16 from_float<__hip_bfloat16>
 
 // v_exp_f32 / v_rcp_f32 (1 ulp) instead of the IEEE division sequence: the gates are fp32 but not bit-critical
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanh_f(float x) {
-  const float c = fminf(fmaxf(x, -15.0f), 15.0f);
-  const float e = __expf(2.0f * c);
-  return (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
-}
+// tanh(x) = 1 - 2 / (1 + e^{2x}): saturates correctly (e = inf -> 1, e = 0 -> -1) without a clamp
+__device__ __forceinline__ float tanh_f(float x) { return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)), 1.0f); }
 
 // 4 consecutive hidden units of one sequence, as stored in global memory
 template <typename T> struct Vec4;
@@ -75,7 +72,7 @@ __device__ __forceinline__ void pack4(const float (&f)[4], uint2& v) { v = make_
 struct GruFwdArgs {
   const void* gi;        // [B][T][2][3H]   (x W_ih^T + b_ih, both directions)
   const __hip_bfloat16* w_hh;   // [2][3H][H]
-  const float* b_hh;     // [2][3H]
+  const float* b_hn;     // [2][H]    recurrent bias of the n gate (the r / z biases are folded into gi)
   void* y;               // [B][T][2H]
   float* saved;          // [B][T][2][4][H]  r, z, n, gh_n, always fp32 (nullptr: inference)
   long B, T;
@@ -97,7 +94,7 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
   const int q = lane >> 4, c = lane & 15;
   const int dir = blockIdx.y;
   const long row0 = static_cast<long>(blockIdx.x) * kRows;
-  const float* bh = a.b_hh + dir * kG;
+  const float* bh = a.b_hn + dir * kH;
   const T* gi = static_cast<const T*>(a.gi);
   T* y = static_cast<T*>(a.y);
   float* saved = a.saved;
@@ -105,16 +102,13 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
   const bool valid = kFull || b < a.B;
   const long bb = valid ? b : 0;           // rows past the batch compute on row 0's data and store nothing
 
-  float bias[2][3][4];
+  float bias_n[2][4];
   float h_prev[2][4];
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int unit = 32 * wave + 16 * s + 4 * q + i;
-      bias[s][0][i] = bh[unit];
-      bias[s][1][i] = bh[kH + unit];
-      bias[s][2][i] = bh[2 * kH + unit];
+      bias_n[s][i] = bh[32 * wave + 16 * s + 4 * q + i];
       h_prev[s][i] = 0.0f;
     }
 
@@ -144,23 +138,34 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
       unpack4(g_cur[s][2], gin[s]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        acc_r[s][i] = gr[i] + bias[s][0][i];
-        acc_z[s][i] = gz[i] + bias[s][1][i];
-        acc_n[s][i] = bias[s][2][i];
+        acc_r[s][i] = gr[i];               // gi already holds b_ih + b_hh for the r and z gates
+        acc_z[s][i] = gz[i];
+        acc_n[s][i] = bias_n[s][i];
       }
     }
-    // ---- gh^T = W_hh h^T : B fragments (k, n = sequence c) of h_{t-1} from LDS
+    // ---- gh^T = W_hh h^T : B fragments (k, n = sequence c) of h_{t-1} and the n-gate A fragments from LDS,
+    // read one k-step ahead of the MFMAs that consume them (the LDS latency hides under 6 MFMAs)
     const __hip_bfloat16* hrow = hbuf + (cur * kRows + c) * kHPitch + 8 * q;
+    const bf16x8* wnp = wn_lds + wave * 2 * 8 * 64 + lane;
+    bf16x8 hfrag = *reinterpret_cast<const bf16x8*>(hrow);
+    bf16x8 wn0 = wnp[0], wn1 = wnp[8 * 64];
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-      const bf16x8 hfrag = *reinterpret_cast<const bf16x8*>(hrow + 32 * kk);
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        acc_r[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[s][kk], hfrag, acc_r[s], 0, 0, 0);
-        acc_z[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wz[s][kk], hfrag, acc_z[s], 0, 0, 0);
-        const bf16x8 wn = wn_lds[((wave * 2 + s) * 8 + kk) * 64 + lane];
-        acc_n[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn, hfrag, acc_n[s], 0, 0, 0);
+      bf16x8 hfrag_n = hfrag, wn0_n = wn0, wn1_n = wn1;
+      if (kk + 1 < 8) {
+        hfrag_n = *reinterpret_cast<const bf16x8*>(hrow + 32 * (kk + 1));
+        wn0_n = wnp[(kk + 1) * 64];
+        wn1_n = wnp[(8 + kk + 1) * 64];
       }
+      acc_r[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[0][kk], hfrag, acc_r[0], 0, 0, 0);
+      acc_z[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wz[0][kk], hfrag, acc_z[0], 0, 0, 0);
+      acc_n[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn0, hfrag, acc_n[0], 0, 0, 0);
+      acc_r[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[1][kk], hfrag, acc_r[1], 0, 0, 0);
+      acc_z[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wz[1][kk], hfrag, acc_z[1], 0, 0, 0);
+      acc_n[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn1, hfrag, acc_n[1], 0, 0, 0);
+      hfrag = hfrag_n;
+      wn0 = wn0_n;
+      wn1 = wn1_n;
     }
     // ---- gates (lane-local: sequence c, units 4q..4q+3 of each tile) and state update
 #pragma unroll
@@ -353,14 +358,23 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[s][i] = keep[s][i];
     const __hip_bfloat16* brow = dgh + c * kDghPitch + 8 * q;
+    const bf16x8* wnp = wn_lds + wave * 2 * 8 * 64 + lane;
+    // LDS fragments are read two k-steps ahead of the MFMAs that consume them
+    bf16x8 d0 = *reinterpret_cast<const bf16x8*>(brow), d1 = *reinterpret_cast<const bf16x8*>(brow + 32);
 #pragma unroll
     for (int kk = 0; kk < 24; ++kk) {
-      const bf16x8 dfrag = *reinterpret_cast<const bf16x8*>(brow + 32 * kk);
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const bf16x8 wfrag = kk < 16 ? wrz[s][kk < 16 ? kk : 0] : wn_lds[((wave * 2 + s) * 8 + (kk - 16)) * 64 + lane];
-        acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag, dfrag, acc[s], 0, 0, 0);
+      bf16x8 d2 = d1;
+      if (kk + 2 < 24) d2 = *reinterpret_cast<const bf16x8*>(brow + 32 * (kk + 2));
+      if (kk < 16) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wrz[0][kk < 16 ? kk : 0], d0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wrz[1][kk < 16 ? kk : 0], d0, acc[1], 0, 0, 0);
+      } else {
+        const bf16x8 w0 = wnp[(kk - 16) * 64], w1 = wnp[(8 + kk - 16) * 64];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, d0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, d0, acc[1], 0, 0, 0);
       }
+      d0 = d1;
+      d1 = d2;
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -411,15 +425,15 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_backward_kernel(GruBwdArgs
 
 extern "C" {
 
-int seld_gru_forward(const void* gi, int is_bf16, const void* w_hh_bf16, const float* b_hh, int64_t B, int64_t T,
+int seld_gru_forward(const void* gi, int is_bf16, const void* w_hh_bf16, const float* b_hn, int64_t B, int64_t T,
                      int64_t H, void* y, float* saved, void* stream_) {
   using namespace seld;
   DeviceState* st = current_state();
   if (!st) return kErrNotInitialised;
   if (H != kH) return fail(kErrUnsupported, "seld_gru_forward: built for hidden size 256 (config.py:45)");
   if (B <= 0 || T <= 0) return fail(kErrInvalidArgument, "seld_gru_forward: B and T must be positive");
-  if (!gi || !w_hh_bf16 || !b_hh || !y) return fail(kErrInvalidArgument, "seld_gru_forward: null pointer");
-  GruFwdArgs a{gi, static_cast<const __hip_bfloat16*>(w_hh_bf16), b_hh, y, saved, B, T};
+  if (!gi || !w_hh_bf16 || !b_hn || !y) return fail(kErrInvalidArgument, "seld_gru_forward: null pointer");
+  GruFwdArgs a{gi, static_cast<const __hip_bfloat16*>(w_hh_bf16), b_hn, y, saved, B, T};
   const dim3 grid(static_cast<unsigned>((B + kRows - 1) / kRows), 2);
   const size_t lds = kWnBytes + 2 * kRows * kHPitch * sizeof(__hip_bfloat16);
   hipStream_t stream = static_cast<hipStream_t>(stream_);

@@ -28,10 +28,13 @@ class _BiGRULayer(torch.autograd.Function):
         cdt = torch.bfloat16 if low else torch.float32
         with torch.autocast(device_type="cuda", enabled=False):
             xc = x.to(cdt)
-            gi = F.linear(xc, w_ih.to(cdt), b_ih.to(cdt))                       # [B, T, 6H]
+            # the r / z recurrent biases commute with the sigmoid argument: fold them into the GEMM's bias
+            fold = b_hh.clone()
+            fold[:, 2 * HIDDEN:] = 0
+            gi = F.linear(xc, w_ih.to(cdt), (b_ih + fold.reshape(-1)).to(cdt))   # [B, T, 6H]
             b, t, _ = gi.shape
             need = x.requires_grad or w_ih.requires_grad or w_hh.requires_grad
-            y, saved = seld_native.gru_forward(gi.view(b, t, 2, 3 * HIDDEN), w_hh, b_hh, need)
+            y, saved = seld_native.gru_forward(gi.view(b, t, 2, 3 * HIDDEN), w_hh, b_hh[:, 2 * HIDDEN:], need)
         ctx.save_for_backward(xc, w_ih, w_hh, y, saved if saved is not None else torch.empty(0))
         ctx.cdt = cdt
         return y

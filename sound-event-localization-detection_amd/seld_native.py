@@ -269,8 +269,9 @@ def softmax_mse(logits: torch.Tensor, labels: torch.Tensor, grad_scale: float | 
 
 # --------------------------------------------------------------------------- GRU recurrence
 
-def gru_forward(gi: torch.Tensor, w_hh: torch.Tensor, b_hh: torch.Tensor, need_saved: bool):
-    """gi [B, T, 2, 3H] (fp32 / bf16), w_hh [2, 3H, H], b_hh [2, 3H] -> (y [B, T, 2H], saved or None)."""
+def gru_forward(gi: torch.Tensor, w_hh: torch.Tensor, b_hn: torch.Tensor, need_saved: bool):
+    """gi [B, T, 2, 3H] (fp32 / bf16; must already include b_ih and the r/z part of b_hh), w_hh [2, 3H, H],
+    b_hn [2, H] (n-gate recurrent bias) -> (y [B, T, 2H], saved or None)."""
     if not gi.is_cuda:
         raise SeldNativeError("gru_forward: tensors must live on the GPU")
     b, t, two, g3 = gi.shape
@@ -280,7 +281,9 @@ def gru_forward(gi: torch.Tensor, w_hh: torch.Tensor, b_hh: torch.Tensor, need_s
     index = ensure_init(gi.device)
     gi = gi.contiguous()
     w = w_hh.to(torch.bfloat16).contiguous()
-    bias = b_hh.to(torch.float32).contiguous()
+    bias = b_hn.to(torch.float32).contiguous()
+    if tuple(bias.shape) != (2, h):
+        raise ValueError("gru_forward: b_hn must be [2, H]")
     y = torch.empty((b, t, 2 * h), dtype=gi.dtype, device=gi.device)
     saved = torch.empty((b, t, 2, 4, h), dtype=torch.float32, device=gi.device) if need_saved else None
     with torch.cuda.device(index):

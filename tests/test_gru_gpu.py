@@ -29,9 +29,11 @@ def test_forward_matches_bf16_aware_oracle(gpu_device, batch, steps):
     w_ih, b_ih, w_hh, b_hh = _params(64, 1)
     g = torch.Generator().manual_seed(2)
     x = torch.randn(batch, steps, 64, generator=g)
-    gi = torch.stack([torch.nn.functional.linear(x, w_ih[d], b_ih[d]) for d in range(2)], dim=2)   # [B,T,2,3H]
-    y, saved = seld_native.gru_forward(gi.to(gpu_device), torch.stack(w_hh).to(gpu_device),
-                                       torch.stack(b_hh).to(gpu_device), True)
+    # the C ABI takes gi with b_ih AND the r/z part of b_hh folded in, plus the n-gate recurrent bias
+    fold = [torch.cat([b_hh[d][:2 * H], torch.zeros(H)]) for d in range(2)]
+    gi = torch.stack([torch.nn.functional.linear(x, w_ih[d], b_ih[d] + fold[d]) for d in range(2)], dim=2)   # [B,T,2,3H]
+    b_hn = torch.stack([b_hh[d][2 * H:] for d in range(2)])
+    y, saved = seld_native.gru_forward(gi.to(gpu_device), torch.stack(w_hh).to(gpu_device), b_hn.to(gpu_device), True)
     ref = ogru.bigru_layer(x, w_ih, b_ih, w_hh, b_hh, exact=False)
     assert tuple(y.shape) == (batch, steps, 2 * H) and tuple(saved.shape) == (batch, steps, 2, 4, H)
     assert (y.cpu() - ref).abs().max().item() <= 2e-3
