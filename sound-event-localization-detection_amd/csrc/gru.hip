@@ -127,6 +127,9 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
     // operands of the next step, one full step of cover.  Unconditional (index clamped at the last step):
     // a branch here would make the compiler lose count of the outstanding loads and wait vmcnt(0) at once.
     load_gi(t + 1 < a.T ? t + 1 : a.T - 1, g_next);
+    // pin the prefetch here: the scheduler otherwise sinks it below this step's stores (to shorten live
+    // ranges), and then the in-order vmcnt makes the next step wait for those stores' round trip
+    __builtin_amdgcn_sched_barrier(0);
 
     f32x4 acc_r[2], acc_z[2], acc_n[2];
     float gin[2][4];
@@ -202,12 +205,17 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
 
   V4 g_a[2][3], g_b[2][3];                 // ping-pong operand sets (no register copies -> no forced waits)
   load_gi(0, g_a);
+  // The first step is peeled so that the loop is ENTERED in the same memory-queue state as the back edge
+  // leaves it ([6 prefetch loads][10 stores]); otherwise the compiler merges the two states conservatively
+  // and every step waits for the previous step's stores (vmcnt(1) instead of vmcnt(16)).
+  step(0, g_a, g_b);
+  long t = 1;
 #pragma unroll 1
-  for (long t = 0; t + 1 < a.T; t += 2) {    // branch-free steady state: two steps per trip
-    step(t, g_a, g_b);
-    step(t + 1, g_b, g_a);
+  for (; t + 1 < a.T; t += 2) {              // branch-free steady state: two steps per trip
+    step(t, g_b, g_a);
+    step(t + 1, g_a, g_b);
   }
-  if (a.T & 1) step(a.T - 1, g_a, g_b);
+  if (t < a.T) step(t, g_b, g_a);
 }
 
 template <typename T>
@@ -306,6 +314,7 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
   auto step = [&](long t, const GruStepIn<T>& cur_in, GruStepIn<T>& next_in) {
     const long tt = time_of(t);
     load_step(t > 0 ? t - 1 : 0, next_in);         // unconditional, clamped (see the forward kernel)
+    __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ahead of this step's stores
     float keep[2][4];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -385,13 +394,15 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
 
   GruStepIn<T> in_a, in_b;
   load_step(a.T - 1, in_a);
-  long t = a.T - 1;                               // reverse of the forward processing order
+  // reverse of the forward processing order; first step peeled (see the forward kernel)
+  step(a.T - 1, in_a, in_b);
+  long t = a.T - 2;
 #pragma unroll 1
   for (; t >= 1; t -= 2) {
-    step(t, in_a, in_b);
-    step(t - 1, in_b, in_a);
+    step(t, in_b, in_a);
+    step(t - 1, in_a, in_b);
   }
-  if (t == 0) step(0, in_a, in_b);
+  if (t == 0) step(0, in_b, in_a);
 }
 
 template <typename T>

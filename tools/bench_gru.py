@@ -1,0 +1,40 @@
+"""GRU recurrence micro-benchmark (developer tool; target of rocprofv3 --pmc passes).
+usage: python tools/bench_gru.py [batch] [steps] [reps]"""
+import sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "sound-event-localization-detection_amd")]
+import torch
+import seld_native
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 250
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+H = 256
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+gi = (torch.randn(B, T, 2, 3 * H, device=dev) * 0.5).to(torch.bfloat16)
+w = (torch.rand(2, 3 * H, H, device=dev) * 2 - 1) / 16
+bn = torch.zeros(2, H, device=dev)
+dy = torch.randn(B, T, 2 * H, device=dev).to(torch.bfloat16)
+
+
+def timeit(fn):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+y, saved = seld_native.gru_forward(gi, w, bn, True)
+t_f = timeit(lambda: seld_native.gru_forward(gi, w, bn, True))
+t_b = timeit(lambda: seld_native.gru_backward(dy, y, saved, w))
+flop = 2 * B * T * 2 * H * 3 * H * 2          # per kernel (both directions)
+print(f"gru B={B} T={T}: forward {t_f * 1e3:.0f} us ({t_f * 1e3 / T:.2f} us/step, {flop / t_f / 1e9:.1f} TFLOP/s) "
+      f"backward {t_b * 1e3:.0f} us ({t_b * 1e3 / T:.2f} us/step)")
