@@ -91,24 +91,29 @@ int seld_softmax_mse(const void* logits, int logits_is_bf16, const uint16_t* mas
                      void* workspace, void* stream);
 
 /* ---- recurrence: nn.GRU(2048, 256, num_layers=2, bidirectional) at model_crnn.py:65-72 ------- */
-/* One bidirectional GRU layer's recurrence, all T steps in one launch (both directions).
- *   gi      [B][T][2][3H]  input projections x W_ih^T + b_ih, gate order r|z|n, direction 0 = forward in
- *                          time, 1 = reverse (fp32, or bf16 when is_bf16).  The recurrent biases of the r and
- *                          z gates (b_hh[0:2H]) must ALREADY be added into gi (they commute with the sigmoid
- *                          argument); only the n-gate bias stays separate because it sits inside r * (.)
- *   w_hh    [2][3H][H] bf16,  b_hn [2][H] fp32 (= b_hh[2H:3H] per direction),  h0 = 0
- *   y       [B][T][2H]     h_t, forward direction in [..., :H], reverse in [..., H:] (dtype of gi)
- *   saved   [B][T][2][4][H] fp32: r, z, n, (W_hn h + b_hn) per step for the backward pass, or NULL
- * H must be 256.  MFMA bf16 inputs, fp32 accumulation, fp32 gates and state. */
-int seld_gru_forward(const void* gi, int is_bf16, const void* w_hh_bf16, const float* b_hn, int64_t B, int64_t T,
-                     int64_t H, void* y, float* saved, void* stream);
+/* One bidirectional GRU layer's recurrence, all T steps in one launch (both directions), H = 256.
+ * The batch is processed in tiles of seld_gru_tile_rows() = 16 sequences (pad B up to a whole tile).
+ *
+ * Streamed per-step tensors use the kernels' private TILE LAYOUT so that every wavefront load / store
+ * is one contiguous 512 B / 1 KB run: a tensor X[b][t][dir][slot][u] (b = 16*tile + c, u = 32*w + 16*s +
+ * 4*q + i) is stored as  [tile][t][dir][w(8)][s(2)][slot(NS)][q(4)][c(16)][i(4)]  (seld_native.to_tile /
+ * from_tile do the permutes).
+ *   gi_tile    NS=3  input projections x W_ih^T + b_ih, gates r|z|n, direction 0 = forward in time,
+ *                    1 = reverse (fp32, or bf16 when is_bf16).  The recurrent biases of the r and z gates
+ *                    (b_hh[0:2H]) must ALREADY be added in (they commute with the sigmoid argument).
+ *   w_hh       [2][3H][H] bf16;   b_hn [2][H] fp32 (= b_hh[2H:3H] per direction);   h0 = 0
+ *   y          [tiles*16][T][2H] natural layout (h_t; forward direction in [..., :H]), dtype of gi
+ *   saved_tile NS=5  fp32: r, z, n, (W_hn h + b_hn), h per step for the backward pass, or NULL
+ * MFMA bf16 operands, fp32 accumulation, fp32 gates and state. */
+int64_t seld_gru_tile_rows(void);
+int seld_gru_forward(const void* gi_tile, int is_bf16, const void* w_hh_bf16, const float* b_hn, int64_t tiles,
+                     int64_t T, int64_t H, void* y, float* saved_tile, void* stream);
 
-/* Backward of the recurrence.  dy [B][T][2H] (dtype of y), w_hh_t [2][H][3H] bf16 (W_hh transposed).
- * dg [B][T][2][4][H] (dtype of y): da_r, da_z, da_n, da_n*r -- the first three are d/d(gi); slots
- * (0, 1, 3) are d/d(gh), from which the caller forms dW_hh = dgh^T h_prev, db_hh, and with gi's GEMM
- * dW_ih, db_ih, dx. */
-int seld_gru_backward(const void* dy, const void* y, const float* saved, int is_bf16, const void* w_hh_t_bf16,
-                      int64_t B, int64_t T, int64_t H, void* dg, void* stream);
+/* Backward of the recurrence.  dy_tile NS=1 (dtype of y), w_hh_t [2][H][3H] bf16 (W_hh transposed).
+ * dg_tile NS=4 (dtype of y): da_r, da_z, da_n, da_n*r -- the first three are d/d(gi); slots (0, 1, 3) are
+ * d/d(gh), from which the caller forms dW_hh = dgh^T h_prev, db_hh, and with gi's GEMM dW_ih, db_ih, dx. */
+int seld_gru_backward(const void* dy_tile, const float* saved_tile, int is_bf16, const void* w_hh_t_bf16,
+                      int64_t tiles, int64_t T, int64_t H, void* dg_tile, void* stream);
 
 #ifdef __cplusplus
 }

@@ -69,38 +69,46 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ void pack4(const float (&f)[4], float4& v) { v = make_float4(f[0], f[1], f[2], f[3]); }
 __device__ __forceinline__ void pack4(const float (&f)[4], uint2& v) { v = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3])); }
 
+// ---- private "tile" layout of every per-step tensor the kernels stream (gi, saved gates, dy, dg) --------
+// A lane (q = lane>>4, c = lane&15) of wavefront w owns sequence c of its 16-sequence tile and units
+// 32w + 16s + 4q .. +3.  Storing the 4-unit group of lane `lane` at
+//     group(tile, t, dir, w, s, slot, lane) = ((((((tile*T + t)*2 + dir)*8 + w)*2 + s)*NS + slot)*64 + lane)
+// (x4 elements) makes every load / store instruction of a wavefront ONE contiguous 512 B / 1 KB run.
+// In the natural [B][T][...][H] layout the same instruction touches 16 rows x 32..64 B: measured, the
+// CU's store path then takes ~1.6 us per step for the 10 stores of a step -- more than all the arithmetic.
+// The host converts gi / dy into this layout and dg back with one permute each (tens of MB, microseconds).
+__device__ __forceinline__ long tile_group(long tile, long T, long t, int dir, int w, int s, int ns, int slot, int lane) {
+  return ((((((tile * T + t) * 2 + dir) * 8 + w) * 2 + s) * ns + slot) * 64 + lane);
+}
+
 struct GruFwdArgs {
-  const void* gi;        // [B][T][2][3H]   (x W_ih^T + b_ih, both directions)
+  const void* gi;        // tile layout, NS = 3 (r | z | n), dtype T; r/z already include b_hh
   const __hip_bfloat16* w_hh;   // [2][3H][H]
-  const float* b_hn;     // [2][H]    recurrent bias of the n gate (the r / z biases are folded into gi)
-  void* y;               // [B][T][2H]
-  float* saved;          // [B][T][2][4][H]  r, z, n, gh_n, always fp32 (nullptr: inference)
-  long B, T;
+  const float* b_hn;     // [2][H]    recurrent bias of the n gate
+  void* y;               // [tiles*16][T][2H]  natural layout (what the next layer's GEMM reads), dtype T
+  float* saved;          // tile layout, NS = 5 (r, z, n, gh_n, h), always fp32 (nullptr: inference)
+  long tiles, T;
 };
 
-// The MFMA computes gh^T = W_hh h^T: M = gate rows (units), N = the 16 sequences of the tile.  With
-// D[m = 4q+i][n = c] lane (q, c) owns sequence c and the 4 CONSECUTIVE units 4q..4q+3 of each 16-unit
-// tile, so every global / LDS access of the gate math is an 8- or 16-byte vector.
-//
-// kFull (all 16 sequences of the tile exist) and kSave are compile-time so that the step body has NO
-// divergent control flow around its stores: the compiler can then count outstanding stores and wait with
-// vmcnt(N) for the prefetched operands only, instead of draining every store each step (vmcnt(0)).
-template <typename T, bool kFull, bool kSave>
+// The MFMA computes gh^T = W_hh h^T: M = gate rows (units), N = the 16 sequences of the tile; with
+// D[m = 4q+i][n = c] the gate math of a lane is local and every access is an 8- or 16-byte vector.
+// The step body has NO divergent control flow (batch padded to whole tiles by the host; kSave compile
+// time): the compiler counts outstanding loads / stores exactly and never drains the queue.
+template <typename T, bool kSave>
 __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* wn_lds, __hip_bfloat16* hbuf,
                                                   const bf16x8 (&wr)[2][8], const bf16x8 (&wz)[2][8]) {
   typedef typename Vec4<T>::type V4;
+  constexpr bool kLdsY = sizeof(T) == 2;   // bf16: y rows are written from the LDS h tile (512-B runs)
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int q = lane >> 4, c = lane & 15;
   const int dir = blockIdx.y;
-  const long row0 = static_cast<long>(blockIdx.x) * kRows;
+  const long tile = blockIdx.x;
   const float* bh = a.b_hn + dir * kH;
-  const T* gi = static_cast<const T*>(a.gi);
+  const V4* gi = static_cast<const V4*>(a.gi);
   T* y = static_cast<T*>(a.y);
-  float* saved = a.saved;
-  const long b = row0 + c;                 // this lane's sequence
-  const bool valid = kFull || b < a.B;
-  const long bb = valid ? b : 0;           // rows past the batch compute on row 0's data and store nothing
+  float4* saved = reinterpret_cast<float4*>(a.saved);
+  const long b = tile * kRows + c;         // this lane's sequence (natural-layout row)
 
   float bias_n[2][4];
   float h_prev[2][4];
@@ -114,31 +122,28 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
 
   auto time_of = [&](long step) { return dir == 0 ? step : a.T - 1 - step; };
   auto load_gi = [&](long step, V4 (&g)[2][3]) {
-    const T* p = gi + ((bb * a.T + time_of(step)) * 2 + dir) * kG + 32 * wave + 4 * q;
+    // one base pointer per step + compile-time offsets (s*3*64 + gate*64 groups): a single address register
+    const V4* p = gi + tile_group(tile, a.T, time_of(step), dir, wave, 0, 3, 0, lane);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int gate = 0; gate < 3; ++gate) g[s][gate] = *reinterpret_cast<const V4*>(p + gate * kH + 16 * s);
+      for (int gate = 0; gate < 3; ++gate) g[s][gate] = p[(s * 3 + gate) * 64];
   };
 
-  auto step = [&](long t, const V4 (&g_cur)[2][3], V4 (&g_next)[2][3]) {
+  // `g` holds this step's operands on entry; they are unpacked at once and the SAME registers then receive
+  // the next step's operands (a whole step of cover), so no second operand set is needed.
+  auto step = [&](long t, V4 (&g)[2][3]) {
     const long tt = time_of(t);
     const int cur = static_cast<int>(t & 1), nxt = cur ^ 1;
-    // operands of the next step, one full step of cover.  Unconditional (index clamped at the last step):
-    // a branch here would make the compiler lose count of the outstanding loads and wait vmcnt(0) at once.
-    load_gi(t + 1 < a.T ? t + 1 : a.T - 1, g_next);
-    // pin the prefetch here: the scheduler otherwise sinks it below this step's stores (to shorten live
-    // ranges), and then the in-order vmcnt makes the next step wait for those stores' round trip
-    __builtin_amdgcn_sched_barrier(0);
-
+    float4* const save_base = kSave ? saved + tile_group(tile, a.T, tt, dir, wave, 0, 5, 0, lane) : nullptr;
     f32x4 acc_r[2], acc_z[2], acc_n[2];
     float gin[2][4];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       float gr[4], gz[4];
-      unpack4(g_cur[s][0], gr);
-      unpack4(g_cur[s][1], gz);
-      unpack4(g_cur[s][2], gin[s]);
+      unpack4(g[s][0], gr);
+      unpack4(g[s][1], gz);
+      unpack4(g[s][2], gin[s]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         acc_r[s][i] = gr[i];               // gi already holds b_ih + b_hh for the r and z gates
@@ -146,6 +151,12 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
         acc_n[s][i] = bias_n[s][i];
       }
     }
+    // operands of the next step: unconditional (clamped at the last step) and pinned here -- the scheduler
+    // otherwise sinks the loads below this step's stores, and the in-order vmcnt then makes the next step
+    // wait for those stores' round trip.
+    __builtin_amdgcn_sched_barrier(0);
+    load_gi(t + 1 < a.T ? t + 1 : a.T - 1, g);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- gh^T = W_hh h^T : B fragments (k, n = sequence c) of h_{t-1} and the n-gate A fragments from LDS,
     // read one k-step ahead of the MFMAs that consume them (the LDS latency hides under 6 MFMAs)
     const __hip_bfloat16* hrow = hbuf + (cur * kRows + c) * kHPitch + 8 * q;
@@ -187,35 +198,37 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
       uint2 hb;
       pack4(hh, hb);
       *reinterpret_cast<uint2*>(hbuf + (nxt * kRows + c) * kHPitch + unit0) = hb;
-      if (kFull || valid) {
+      if (!kLdsY) {
         V4 yv;
         pack4(hh, yv);
         *reinterpret_cast<V4*>(y + (b * a.T + tt) * (2 * kH) + dir * kH + unit0) = yv;
-        if (kSave) {
-          float* sp = saved + (((b * a.T + tt) * 2 + dir) * 4) * kH + unit0;
-          *reinterpret_cast<float4*>(sp) = make_float4(rr[0], rr[1], rr[2], rr[3]);
-          *reinterpret_cast<float4*>(sp + kH) = make_float4(zz[0], zz[1], zz[2], zz[3]);
-          *reinterpret_cast<float4*>(sp + 2 * kH) = make_float4(nn[0], nn[1], nn[2], nn[3]);
-          *reinterpret_cast<float4*>(sp + 3 * kH) = make_float4(gg[0], gg[1], gg[2], gg[3]);
-        }
+      }
+      if (kSave) {
+        float4* sp = save_base + s * 5 * 64;
+        sp[0] = make_float4(rr[0], rr[1], rr[2], rr[3]);
+        sp[64] = make_float4(zz[0], zz[1], zz[2], zz[3]);
+        sp[128] = make_float4(nn[0], nn[1], nn[2], nn[3]);
+        sp[192] = make_float4(gg[0], gg[1], gg[2], gg[3]);
+        sp[256] = make_float4(hh[0], hh[1], hh[2], hh[3]);
       }
     }
     __syncthreads();
+    if (kLdsY) {
+      // y[b][tt][dir*H .. +H) is a 512-B run: wavefront w writes rows 2w and 2w+1 of the fresh h tile
+      const int row = 2 * wave + (lane >> 5), col = (lane & 31) * 8;
+      const uint4 v = *reinterpret_cast<const uint4*>(hbuf + (nxt * kRows + row) * kHPitch + col);
+      *reinterpret_cast<uint4*>(y + ((tile * kRows + row) * a.T + tt) * (2 * kH) + dir * kH + col) = v;
+    }
   };
 
-  V4 g_a[2][3], g_b[2][3];                 // ping-pong operand sets (no register copies -> no forced waits)
-  load_gi(0, g_a);
+  V4 g[2][3];
+  load_gi(0, g);
   // The first step is peeled so that the loop is ENTERED in the same memory-queue state as the back edge
-  // leaves it ([6 prefetch loads][10 stores]); otherwise the compiler merges the two states conservatively
-  // and every step waits for the previous step's stores (vmcnt(1) instead of vmcnt(16)).
-  step(0, g_a, g_b);
-  long t = 1;
+  // leaves it; otherwise the compiler merges the two states conservatively and every step waits for the
+  // previous step's stores.
+  step(0, g);
 #pragma unroll 1
-  for (; t + 1 < a.T; t += 2) {              // branch-free steady state: two steps per trip
-    step(t, g_b, g_a);
-    step(t + 1, g_a, g_b);
-  }
-  if (t < a.T) step(t, g_b, g_a);
+  for (long t = 1; t < a.T; ++t) step(t, g);
 }
 
 template <typename T>
@@ -244,33 +257,25 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs 
   }
   for (int i = tid; i < 2 * kRows * kHPitch; i += kGruThreads) hbuf[i] = __float2bfloat16(0.0f);
   __syncthreads();
-
-  const bool full = static_cast<long>(blockIdx.x) * kRows + kRows <= a.B;     // workgroup-uniform
-  if (a.saved) {
-    if (full) gru_forward_steps<T, true, true>(a, wn_lds, hbuf, wr, wz);
-    else gru_forward_steps<T, false, true>(a, wn_lds, hbuf, wr, wz);
-  } else {
-    if (full) gru_forward_steps<T, true, false>(a, wn_lds, hbuf, wr, wz);
-    else gru_forward_steps<T, false, false>(a, wn_lds, hbuf, wr, wz);
-  }
+  if (a.saved) gru_forward_steps<T, true>(a, wn_lds, hbuf, wr, wz);
+  else gru_forward_steps<T, false>(a, wn_lds, hbuf, wr, wz);
 }
 
 struct GruBwdArgs {
-  const void* dy;        // [B][T][2H]
-  const void* y;         // [B][T][2H]        forward outputs (h_t)
-  const float* saved;    // [B][T][2][4][H]   r, z, n, gh_n (fp32)
+  const void* dy;        // tile layout, NS = 1, dtype T
+  const float* saved;    // tile layout, NS = 5 (r, z, n, gh_n, h), fp32
   const __hip_bfloat16* w_hh_t;   // [2][H][3H]   W_hh transposed per direction
-  void* dg;              // [B][T][2][4][H]   da_r, da_z, da_n, da_n * r
-  long B, T;
+  void* dg;              // tile layout, NS = 4 (da_r, da_z, da_n, da_n * r), dtype T
+  long tiles, T;
 };
 
 template <typename T> struct GruStepIn {
-  float4 r[2], z[2], n[2], g[2];
-  typename Vec4<T>::type hp[2], d[2];
+  float4 r[2], z[2], n[2], g[2], hp[2];
+  typename Vec4<T>::type d[2];
 };
 
 // dh_prev^T = W_hh^T dgh^T : M = hidden units, N = sequences; same lane ownership as the forward kernel.
-template <typename T, bool kFull>
+template <typename T>
 __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* wn_lds, __hip_bfloat16* dgh,
                                                    const bf16x8 (&wrz)[2][16]) {
   typedef typename Vec4<T>::type V4;
@@ -278,14 +283,10 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
   const int wave = tid >> 6, lane = tid & 63;
   const int q = lane >> 4, c = lane & 15;
   const int dir = blockIdx.y;
-  const long row0 = static_cast<long>(blockIdx.x) * kRows;
-  const T* dy = static_cast<const T*>(a.dy);
-  const T* y = static_cast<const T*>(a.y);
-  const float* saved = a.saved;
-  T* dg = static_cast<T*>(a.dg);
-  const long b = row0 + c;
-  const bool valid = kFull || b < a.B;
-  const long bb = valid ? b : 0;
+  const long tile = blockIdx.x;
+  const V4* dy = static_cast<const V4*>(a.dy);
+  const float4* saved = reinterpret_cast<const float4*>(a.saved);
+  V4* dg = static_cast<V4*>(a.dg);
 
   float dh[2][4];
 #pragma unroll
@@ -296,60 +297,66 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
   auto time_of = [&](long step) { return dir == 0 ? step : a.T - 1 - step; };
   auto load_step = [&](long step, GruStepIn<T>& in) {
     const long tt = time_of(step);
-    const float* sp = saved + (((bb * a.T + tt) * 2 + dir) * 4) * kH + 32 * wave + 4 * q;
-    const T* dp = dy + (bb * a.T + tt) * (2 * kH) + dir * kH + 32 * wave + 4 * q;
-    const long tprev = dir == 0 ? tt - 1 : tt + 1;
-    const T* hp = y + (bb * a.T + (step > 0 ? tprev : tt)) * (2 * kH) + dir * kH + 32 * wave + 4 * q;
+    const long tprev = time_of(step > 0 ? step - 1 : 0);      // h_{t-1} of the forward recurrence (unused at step 0)
+    const float4* sp0 = saved + tile_group(tile, a.T, tt, dir, wave, 0, 5, 0, lane);
+    const float4* hp0 = saved + tile_group(tile, a.T, tprev, dir, wave, 0, 5, 4, lane);
+    const V4* dp0 = dy + tile_group(tile, a.T, tt, dir, wave, 0, 1, 0, lane);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      in.r[s] = *reinterpret_cast<const float4*>(sp + 16 * s);
-      in.z[s] = *reinterpret_cast<const float4*>(sp + kH + 16 * s);
-      in.n[s] = *reinterpret_cast<const float4*>(sp + 2 * kH + 16 * s);
-      in.g[s] = *reinterpret_cast<const float4*>(sp + 3 * kH + 16 * s);
-      in.d[s] = *reinterpret_cast<const V4*>(dp + 16 * s);
-      in.hp[s] = *reinterpret_cast<const V4*>(hp + 16 * s);
+      in.r[s] = sp0[s * 5 * 64];
+      in.z[s] = sp0[s * 5 * 64 + 64];
+      in.n[s] = sp0[s * 5 * 64 + 128];
+      in.g[s] = sp0[s * 5 * 64 + 192];
+      in.hp[s] = hp0[s * 5 * 64];
+      in.d[s] = dp0[s * 64];
     }
   };
 
-  auto step = [&](long t, const GruStepIn<T>& cur_in, GruStepIn<T>& next_in) {
+  // `in` holds this step's operands on entry; they are unpacked at once and the same registers then receive
+  // the operands of the next (earlier-in-time) step.
+  auto step = [&](long t, GruStepIn<T>& in) {
     const long tt = time_of(t);
-    load_step(t > 0 ? t - 1 : 0, next_in);         // unconditional, clamped (see the forward kernel)
-    __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ahead of this step's stores
+    float r[2][4], z[2][4], n[2][4], g[2][4], hp[2][4], d[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      unpack4(in.r[s], r[s]);
+      unpack4(in.z[s], z[s]);
+      unpack4(in.n[s], n[s]);
+      unpack4(in.g[s], g[s]);
+      unpack4(in.hp[s], hp[s]);
+      unpack4(in.d[s], d[s]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    load_step(t > 0 ? t - 1 : 0, in);              // unconditional, clamped; pinned ahead of this step's stores
+    __builtin_amdgcn_sched_barrier(0);
     float keep[2][4];
+    V4* const dg_base = dg + tile_group(tile, a.T, tt, dir, wave, 0, 4, 0, lane);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int unit0 = 32 * wave + 16 * s + 4 * q;
-      float r[4], z[4], n[4], g[4], hp[4], d[4], da_r[4], da_z[4], da_n[4], dghn[4];
-      unpack4(cur_in.r[s], r);
-      unpack4(cur_in.z[s], z);
-      unpack4(cur_in.n[s], n);
-      unpack4(cur_in.g[s], g);
-      unpack4(cur_in.hp[s], hp);
-      unpack4(cur_in.d[s], d);
+      float da_r[4], da_z[4], da_n[4], dghn[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float hprev = t > 0 ? hp[i] : 0.0f;
-        const float dtot = valid ? d[i] + dh[s][i] : 0.0f;
-        const float dn = dtot * (1.0f - z[i]);
-        const float dz = dtot * (hprev - n[i]);
-        da_n[i] = dn * (1.0f - n[i] * n[i]);
-        da_z[i] = dz * z[i] * (1.0f - z[i]);
-        da_r[i] = da_n[i] * g[i] * r[i] * (1.0f - r[i]);
-        dghn[i] = da_n[i] * r[i];
-        keep[s][i] = dtot * z[i];
+        const float hprev = t > 0 ? hp[s][i] : 0.0f;
+        const float dtot = d[s][i] + dh[s][i];
+        const float dn = dtot * (1.0f - z[s][i]);
+        const float dz = dtot * (hprev - n[s][i]);
+        da_n[i] = dn * (1.0f - n[s][i] * n[s][i]);
+        da_z[i] = dz * z[s][i] * (1.0f - z[s][i]);
+        da_r[i] = da_n[i] * g[s][i] * r[s][i] * (1.0f - r[s][i]);
+        dghn[i] = da_n[i] * r[s][i];
+        keep[s][i] = dtot * z[s][i];
       }
-      if (kFull || valid) {
-        T* gp = dg + (((b * a.T + tt) * 2 + dir) * 4) * kH + unit0;
-        V4 v;
-        pack4(da_r, v);
-        *reinterpret_cast<V4*>(gp) = v;
-        pack4(da_z, v);
-        *reinterpret_cast<V4*>(gp + kH) = v;
-        pack4(da_n, v);
-        *reinterpret_cast<V4*>(gp + 2 * kH) = v;
-        pack4(dghn, v);
-        *reinterpret_cast<V4*>(gp + 3 * kH) = v;
-      }
+      V4* gp = dg_base + s * 4 * 64;
+      V4 v;
+      pack4(da_r, v);
+      gp[0] = v;
+      pack4(da_z, v);
+      gp[64] = v;
+      pack4(da_n, v);
+      gp[128] = v;
+      pack4(dghn, v);
+      gp[192] = v;
       __hip_bfloat16* drow = dgh + c * kDghPitch + unit0;
       uint2 pk;
       pack4(da_r, pk);
@@ -392,17 +399,12 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
     __syncthreads();
   };
 
-  GruStepIn<T> in_a, in_b;
-  load_step(a.T - 1, in_a);
+  GruStepIn<T> in;
+  load_step(a.T - 1, in);
   // reverse of the forward processing order; first step peeled (see the forward kernel)
-  step(a.T - 1, in_a, in_b);
-  long t = a.T - 2;
+  step(a.T - 1, in);
 #pragma unroll 1
-  for (; t >= 1; t -= 2) {
-    step(t, in_b, in_a);
-    step(t - 1, in_a, in_b);
-  }
-  if (t == 0) step(0, in_b, in_a);
+  for (long t = a.T - 2; t >= 0; --t) step(t, in);
 }
 
 template <typename T>
@@ -428,24 +430,25 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_backward_kernel(GruBwdArgs
           *reinterpret_cast<const bf16x8*>(wt + static_cast<long>(unit) * kG + 2 * kH + 32 * kk + 8 * q);
   }
   __syncthreads();
-  if (static_cast<long>(blockIdx.x) * kRows + kRows <= a.B) gru_backward_steps<T, true>(a, wn_lds, dgh, wrz);
-  else gru_backward_steps<T, false>(a, wn_lds, dgh, wrz);
+  gru_backward_steps<T>(a, wn_lds, dgh, wrz);
 }
 
 }  // namespace seld
 
 extern "C" {
 
-int seld_gru_forward(const void* gi, int is_bf16, const void* w_hh_bf16, const float* b_hn, int64_t B, int64_t T,
-                     int64_t H, void* y, float* saved, void* stream_) {
+int64_t seld_gru_tile_rows(void) { return seld::kRows; }
+
+int seld_gru_forward(const void* gi_tile, int is_bf16, const void* w_hh_bf16, const float* b_hn, int64_t tiles,
+                     int64_t T, int64_t H, void* y, float* saved_tile, void* stream_) {
   using namespace seld;
   DeviceState* st = current_state();
   if (!st) return kErrNotInitialised;
   if (H != kH) return fail(kErrUnsupported, "seld_gru_forward: built for hidden size 256 (config.py:45)");
-  if (B <= 0 || T <= 0) return fail(kErrInvalidArgument, "seld_gru_forward: B and T must be positive");
-  if (!gi || !w_hh_bf16 || !b_hn || !y) return fail(kErrInvalidArgument, "seld_gru_forward: null pointer");
-  GruFwdArgs a{gi, static_cast<const __hip_bfloat16*>(w_hh_bf16), b_hn, y, saved, B, T};
-  const dim3 grid(static_cast<unsigned>((B + kRows - 1) / kRows), 2);
+  if (tiles <= 0 || T <= 0) return fail(kErrInvalidArgument, "seld_gru_forward: tiles and T must be positive");
+  if (!gi_tile || !w_hh_bf16 || !b_hn || !y) return fail(kErrInvalidArgument, "seld_gru_forward: null pointer");
+  GruFwdArgs a{gi_tile, static_cast<const __hip_bfloat16*>(w_hh_bf16), b_hn, y, saved_tile, tiles, T};
+  const dim3 grid(static_cast<unsigned>(tiles), 2);
   const size_t lds = kWnBytes + 2 * kRows * kHPitch * sizeof(__hip_bfloat16);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (is_bf16) {
@@ -461,16 +464,17 @@ int seld_gru_forward(const void* gi, int is_bf16, const void* w_hh_bf16, const f
   return kOk;
 }
 
-int seld_gru_backward(const void* dy, const void* y, const float* saved, int is_bf16, const void* w_hh_t_bf16,
-                      int64_t B, int64_t T, int64_t H, void* dg, void* stream_) {
+int seld_gru_backward(const void* dy_tile, const float* saved_tile, int is_bf16, const void* w_hh_t_bf16,
+                      int64_t tiles, int64_t T, int64_t H, void* dg_tile, void* stream_) {
   using namespace seld;
   DeviceState* st = current_state();
   if (!st) return kErrNotInitialised;
   if (H != kH) return fail(kErrUnsupported, "seld_gru_backward: built for hidden size 256 (config.py:45)");
-  if (B <= 0 || T <= 0) return fail(kErrInvalidArgument, "seld_gru_backward: B and T must be positive");
-  if (!dy || !y || !saved || !w_hh_t_bf16 || !dg) return fail(kErrInvalidArgument, "seld_gru_backward: null pointer");
-  GruBwdArgs a{dy, y, saved, static_cast<const __hip_bfloat16*>(w_hh_t_bf16), dg, B, T};
-  const dim3 grid(static_cast<unsigned>((B + kRows - 1) / kRows), 2);
+  if (tiles <= 0 || T <= 0) return fail(kErrInvalidArgument, "seld_gru_backward: tiles and T must be positive");
+  if (!dy_tile || !saved_tile || !w_hh_t_bf16 || !dg_tile)
+    return fail(kErrInvalidArgument, "seld_gru_backward: null pointer");
+  GruBwdArgs a{dy_tile, saved_tile, static_cast<const __hip_bfloat16*>(w_hh_t_bf16), dg_tile, tiles, T};
+  const dim3 grid(static_cast<unsigned>(tiles), 2);
   const size_t lds = kWnBytes + kRows * kDghPitch * sizeof(__hip_bfloat16);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (is_bf16) {

@@ -54,8 +54,10 @@ def _declare(lib):
     lib.seld_softmax_mse_workspace_bytes.restype = _i64
     lib.seld_softmax_mse_workspace_bytes.argtypes = []
     lib.seld_softmax_mse.argtypes = [_ptr, _int, _ptr, _ptr, _i64, _int, ctypes.c_float, _ptr, _ptr, _ptr, _ptr]
+    lib.seld_gru_tile_rows.restype = _i64
+    lib.seld_gru_tile_rows.argtypes = []
     lib.seld_gru_forward.argtypes = [_ptr, _int, _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr]
-    lib.seld_gru_backward.argtypes = [_ptr, _ptr, _ptr, _int, _ptr, _i64, _i64, _i64, _ptr, _ptr]
+    lib.seld_gru_backward.argtypes = [_ptr, _ptr, _int, _ptr, _i64, _i64, _i64, _ptr, _ptr]
     return lib
 
 
@@ -269,38 +271,63 @@ def softmax_mse(logits: torch.Tensor, labels: torch.Tensor, grad_scale: float | 
 
 # --------------------------------------------------------------------------- GRU recurrence
 
+GRU_TILE = 16
+GRU_H = 256
+
+
+def to_tile(x: torch.Tensor, ns: int) -> torch.Tensor:
+    """[B, T, 2, ns, 256] -> the kernels' tile layout [tiles, T, 2, 8, 2, ns, 4, 16, 4] (batch zero-padded to
+    whole 16-sequence tiles).  unit u = 32*w + 16*s + 4*q + i, row b = 16*tile + c."""
+    b, t = x.shape[0], x.shape[1]
+    tiles = (b + GRU_TILE - 1) // GRU_TILE
+    if tiles * GRU_TILE != b:
+        x = torch.cat((x, x.new_zeros((tiles * GRU_TILE - b,) + tuple(x.shape[1:]))), dim=0)
+    x = x.reshape(tiles, GRU_TILE, t, 2, ns, 8, 2, 4, 4)             # tile, c, T, dir, slot, w, s, q, i
+    return x.permute(0, 2, 3, 5, 6, 4, 7, 1, 8).contiguous()         # tile, T, dir, w, s, slot, q, c, i
+
+
+def from_tile(x: torch.Tensor, batch: int) -> torch.Tensor:
+    """Inverse of to_tile: [tiles, T, 2, 8, 2, ns, 4, 16, 4] -> [batch, T, 2, ns, 256]."""
+    tiles, t, ns = x.shape[0], x.shape[1], x.shape[5]
+    y = x.permute(0, 7, 1, 2, 5, 3, 4, 6, 8).reshape(tiles * GRU_TILE, t, 2, ns, GRU_H)
+    return y[:batch]
+
+
 def gru_forward(gi: torch.Tensor, w_hh: torch.Tensor, b_hn: torch.Tensor, need_saved: bool):
     """gi [B, T, 2, 3H] (fp32 / bf16; must already include b_ih and the r/z part of b_hh), w_hh [2, 3H, H],
-    b_hn [2, H] (n-gate recurrent bias) -> (y [B, T, 2H], saved or None)."""
+    b_hn [2, H] (n-gate recurrent bias) -> (y [B, T, 2H], saved (tile layout, opaque) or None)."""
     if not gi.is_cuda:
         raise SeldNativeError("gru_forward: tensors must live on the GPU")
     b, t, two, g3 = gi.shape
     h = g3 // 3
-    if two != 2 or gi.dtype not in (torch.float32, torch.bfloat16):
-        raise ValueError("gru_forward: gi must be [B, T, 2, 3H] float32 or bfloat16")
+    if two != 2 or h != GRU_H or gi.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("gru_forward: gi must be [B, T, 2, 768] float32 or bfloat16")
     index = ensure_init(gi.device)
-    gi = gi.contiguous()
+    gi_tile = to_tile(gi.reshape(b, t, 2, 3, h), 3)
+    tiles = gi_tile.shape[0]
     w = w_hh.to(torch.bfloat16).contiguous()
     bias = b_hn.to(torch.float32).contiguous()
     if tuple(bias.shape) != (2, h):
         raise ValueError("gru_forward: b_hn must be [2, H]")
-    y = torch.empty((b, t, 2 * h), dtype=gi.dtype, device=gi.device)
-    saved = torch.empty((b, t, 2, 4, h), dtype=torch.float32, device=gi.device) if need_saved else None
+    y = torch.empty((tiles * GRU_TILE, t, 2 * h), dtype=gi.dtype, device=gi.device)
+    saved = torch.empty((tiles, t, 2, 8, 2, 5, 4, GRU_TILE, 4), dtype=torch.float32, device=gi.device) \
+        if need_saved else None
     with torch.cuda.device(index):
-        check(load_library().seld_gru_forward(_p(gi), int(gi.dtype == torch.bfloat16), _p(w), _p(bias), b, t, h,
-                                              _p(y), _p(saved), _stream_ptr(gi.device)), "seld_gru_forward")
-    return y, saved
+        check(load_library().seld_gru_forward(_p(gi_tile), int(gi.dtype == torch.bfloat16), _p(w), _p(bias), tiles, t,
+                                              h, _p(y), _p(saved), _stream_ptr(gi.device)), "seld_gru_forward")
+    return y[:b], saved
 
 
-def gru_backward(dy: torch.Tensor, y: torch.Tensor, saved: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
-    """-> dg [B, T, 2, 4, H] (da_r, da_z, da_n, da_n*r), dtype of y."""
-    b, t, h2 = y.shape
+def gru_backward(dy: torch.Tensor, saved: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
+    """dy [B, T, 2H] -> dg [B, T, 2, 4, H] (da_r, da_z, da_n, da_n*r), dtype of dy."""
+    b, t, h2 = dy.shape
     h = h2 // 2
-    index = ensure_init(y.device)
-    dy = dy.to(y.dtype).contiguous()
+    index = ensure_init(dy.device)
+    dy_tile = to_tile(dy.reshape(b, t, 2, 1, h), 1)
+    tiles = dy_tile.shape[0]
     w_t = w_hh.to(torch.bfloat16).transpose(1, 2).contiguous()            # [2, H, 3H]
-    dg = torch.empty((b, t, 2, 4, h), dtype=y.dtype, device=y.device)
+    dg_tile = torch.empty((tiles, t, 2, 8, 2, 4, 4, GRU_TILE, 4), dtype=dy.dtype, device=dy.device)
     with torch.cuda.device(index):
-        check(load_library().seld_gru_backward(_p(dy), _p(y), _p(saved), int(y.dtype == torch.bfloat16), _p(w_t),
-                                               b, t, h, _p(dg), _stream_ptr(y.device)), "seld_gru_backward")
-    return dg
+        check(load_library().seld_gru_backward(_p(dy_tile), _p(saved), int(dy.dtype == torch.bfloat16), _p(w_t),
+                                               tiles, t, h, _p(dg_tile), _stream_ptr(dy.device)), "seld_gru_backward")
+    return from_tile(dg_tile, b)

@@ -34,7 +34,7 @@ def timeit(fn):
 
 y, saved = seld_native.gru_forward(gi, w, bn, True)
 t_f = timeit(lambda: seld_native.gru_forward(gi, w, bn, True))
-t_b = timeit(lambda: seld_native.gru_backward(dy, y, saved, w))
+t_b = timeit(lambda: seld_native.gru_backward(dy, saved, w))
 flop = 2 * B * T * 2 * H * 3 * H * 2          # per kernel (both directions)
 print(f"gru B={B} T={T}: forward {t_f * 1e3:.0f} us ({t_f * 1e3 / T:.2f} us/step, {flop / t_f / 1e9:.1f} TFLOP/s) "
       f"backward {t_b * 1e3:.0f} us ({t_b * 1e3 / T:.2f} us/step)")
