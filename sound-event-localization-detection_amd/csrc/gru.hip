@@ -451,15 +451,16 @@ int seld_gru_forward(const void* gi_tile, int is_bf16, const void* w_hh_bf16, co
   const dim3 grid(static_cast<unsigned>(tiles), 2);
   const size_t lds = kWnBytes + 2 * kRows * kHPitch * sizeof(__hip_bfloat16);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (is_bf16) {
+  static bool attr_done = false;          // not a stream operation: do it once so launches stay graph-capturable
+  if (!attr_done) {
     SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_forward_kernel<__hip_bfloat16>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    hipLaunchKernelGGL(gru_forward_kernel<__hip_bfloat16>, grid, dim3(kGruThreads), lds, stream, a);
-  } else {
     SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_forward_kernel<float>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    hipLaunchKernelGGL(gru_forward_kernel<float>, grid, dim3(kGruThreads), lds, stream, a);
+    attr_done = true;
   }
+  if (is_bf16) hipLaunchKernelGGL(gru_forward_kernel<__hip_bfloat16>, grid, dim3(kGruThreads), lds, stream, a);
+  else hipLaunchKernelGGL(gru_forward_kernel<float>, grid, dim3(kGruThreads), lds, stream, a);
   SELD_HIP_TRY(hipGetLastError());
   return kOk;
 }
@@ -477,15 +478,16 @@ int seld_gru_backward(const void* dy_tile, const float* saved_tile, int is_bf16,
   const dim3 grid(static_cast<unsigned>(tiles), 2);
   const size_t lds = kWnBytes + kRows * kDghPitch * sizeof(__hip_bfloat16);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (is_bf16) {
+  static bool attr_done = false;
+  if (!attr_done) {
     SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_backward_kernel<__hip_bfloat16>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    hipLaunchKernelGGL(gru_backward_kernel<__hip_bfloat16>, grid, dim3(kGruThreads), lds, stream, a);
-  } else {
     SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_backward_kernel<float>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    hipLaunchKernelGGL(gru_backward_kernel<float>, grid, dim3(kGruThreads), lds, stream, a);
+    attr_done = true;
   }
+  if (is_bf16) hipLaunchKernelGGL(gru_backward_kernel<__hip_bfloat16>, grid, dim3(kGruThreads), lds, stream, a);
+  else hipLaunchKernelGGL(gru_backward_kernel<float>, grid, dim3(kGruThreads), lds, stream, a);
   SELD_HIP_TRY(hipGetLastError());
   return kOk;
 }
