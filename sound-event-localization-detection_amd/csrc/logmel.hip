@@ -202,14 +202,23 @@ static int launch_logmel(const T* pcm, int64_t N, int64_t C, int64_t L, float* o
     attr_done[which] = true;
   }
   const long n_edge = a.rows * a.edge_per_row;
-  hipLaunchKernelGGL(logmel_edge_kernel<T>, dim3(static_cast<unsigned>((n_edge + kEdgeWaves - 1) / kEdgeWaves)),
-                     dim3(kEdgeWaves * 64), kEdgeLdsBytes, stream, a);
-  SELD_HIP_TRY(hipGetLastError());
   const long total = a.rows * a.interior;
+  // The edge kernel (a few hundred latency-bound wavefront-iterations) runs on the library's side stream,
+  // forked from and joined back into the caller's stream with events, so it overlaps the main kernel
+  // (same pattern under stream capture).
+  const bool fork = total > 0;
+  hipStream_t edge_stream = fork ? st->side_stream : stream;
+  if (fork) {
+    SELD_HIP_TRY(hipEventRecord(st->fork_event, stream));
+    SELD_HIP_TRY(hipStreamWaitEvent(st->side_stream, st->fork_event, 0));
+  }
+  hipLaunchKernelGGL(logmel_edge_kernel<T>, dim3(static_cast<unsigned>((n_edge + kEdgeWaves - 1) / kEdgeWaves)),
+                     dim3(kEdgeWaves * 64), kEdgeLdsBytes, edge_stream, a);
+  SELD_HIP_TRY(hipGetLastError());
   if (total > 0) {
-    // one 8-wavefront workgroup per CU (LDS bound); every wavefront gets a contiguous run of >= 16 iterations
+    // one 8-wavefront workgroup per CU (LDS bound); every wavefront gets a contiguous run of >= 8 iterations
     const long max_waves = static_cast<long>(st->num_cus) * kMainWaves;
-    long waves = (total + 15) / 16;
+    long waves = (total + 7) / 8;
     if (waves > max_waves) waves = max_waves;
     a.chunk = (total + waves - 1) / waves;
     const long used_waves = (total + a.chunk - 1) / a.chunk;
@@ -217,6 +226,8 @@ static int launch_logmel(const T* pcm, int64_t N, int64_t C, int64_t L, float* o
     hipLaunchKernelGGL(logmel_main_kernel<T>, dim3(static_cast<unsigned>(grid)), dim3(kMainWaves * 64), kMainLdsBytes,
                        stream, a);
     SELD_HIP_TRY(hipGetLastError());
+    SELD_HIP_TRY(hipEventRecord(st->join_event, st->side_stream));
+    SELD_HIP_TRY(hipStreamWaitEvent(stream, st->join_event, 0));
   }
   return kOk;
 }

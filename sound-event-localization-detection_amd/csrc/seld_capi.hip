@@ -85,6 +85,9 @@ int seld_init(int device) {
   default_mel_filterbank(fb);
   const int rc = upload_mel(st, fb);
   if (rc != kOk) return rc;
+  SELD_HIP_TRY(hipStreamCreateWithFlags(&st.side_stream, hipStreamNonBlocking));
+  SELD_HIP_TRY(hipEventCreateWithFlags(&st.fork_event, hipEventDisableTiming));
+  SELD_HIP_TRY(hipEventCreateWithFlags(&st.join_event, hipEventDisableTiming));
   st.ready = true;
   return kOk;
 }
@@ -102,6 +105,9 @@ int seld_shutdown(void) {
     (void)hipFree(st.mel_wd);
     (void)hipFree(st.mel_wu);
     (void)hipFree(st.mel_fb);
+    (void)hipEventDestroy(st.fork_event);
+    (void)hipEventDestroy(st.join_event);
+    (void)hipStreamDestroy(st.side_stream);
     st = DeviceState();
   }
   g_states.clear();

@@ -39,6 +39,9 @@ struct DeviceState {
   float* mel_wd = nullptr;
   float* mel_wu = nullptr;
   float* mel_fb = nullptr;      // dense [481][64] copy (used by the intensity-vector / debug paths)
+  // side stream + fork/join events: the tiny edge kernel of the log-mel path overlaps the main kernel
+  hipStream_t side_stream = nullptr;
+  hipEvent_t fork_event = nullptr, join_event = nullptr;
   LogmelTables tables() const { return LogmelTables{window, twiddle, mel_b0, mel_wd, mel_wu}; }
 };
 
