@@ -151,6 +151,18 @@ class HotPath:
         return last
 
 
+def measured_traffic_per_clip():
+    """HBM bytes per clip of the log-mel main kernel from the committed rocprofv3 --pmc passes
+    (profiles/*_pmc_logmel_summary.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per clip)."""
+    best = None
+    for path in sorted((ROOT / "profiles").glob("*_pmc_logmel_summary.json")):
+        try:
+            best = (path.name, float(json.loads(path.read_text())["traffic_bytes_per_clip"]))
+        except (ValueError, KeyError):
+            continue
+    return best
+
+
 def cpu_baseline():
     """Oracle path on the host cores, bounded sample (about 20-30 s): log-mel of 2 clips via the
     torch.stft restatement, reference-equivalent CRNN fwd+bwd+Adam at batch 2 (3 iterations after
@@ -240,6 +252,7 @@ def main():
         achieved_gbs = CLIPS_PER_STEP * BYTES_PER_CLIP / (feat_ms * 1e-3) / 1e9
         windows_per_step = CLIPS_PER_STEP * FRAMES_PER_CLIP // HOP
         model_tflops = windows_per_step * GFLOP_PER_WINDOW[args.model] / (model_ms * 1e-3) / 1e3
+        traffic = measured_traffic_per_clip()
         line = {
             "metric": "training clips/sec (4ch FOA 60s@24kHz)",
             "value": clips / elapsed, "unit": "clips/s",
@@ -254,7 +267,9 @@ def main():
                        "final_loss": float(loss.item())},
             "roofline": {"kernel": "seld::logmel_main_kernel<float> + logmel_edge_kernel<float> (fused STFT+mel+dB)", "bound": "hbm",
                          "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved_gbs / HBM_PEAK_GBS,
+                         "traffic": traffic[1] * CLIPS_PER_STEP if traffic else None,
+                         "traffic_source": f"profiles/{traffic[0]} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)" if traffic else None,
                          "bytes_per_launch": CLIPS_PER_STEP * BYTES_PER_CLIP, "avg_launch_ms": feat_ms,
                          "features_only_clips_per_s": CLIPS_PER_STEP / (feat_ms * 1e-3)},
             "roofline_model": {"phase": f"{args.model} fwd+bwd+Adam, {windows_per_step // BATCH} iterations of {BATCH} windows",

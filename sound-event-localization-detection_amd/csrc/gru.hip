@@ -368,11 +368,16 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
     }
     __syncthreads();
 
-    f32x4 acc[2];
+    // two independent accumulator chains per unit tile (even / odd k-steps): with a single chain per tile the
+    // 24 dependent MFMAs of a step run at the MFMA latency, not at its issue rate
+    f32x4 acc[2][2];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[s][i] = keep[s][i];
+      for (int i = 0; i < 4; ++i) {
+        acc[s][0][i] = keep[s][i];
+        acc[s][1][i] = 0.0f;
+      }
     const __hip_bfloat16* brow = dgh + c * kDghPitch + 8 * q;
     const bf16x8* wnp = wn_lds + wave * 2 * 8 * 64 + lane;
     // LDS fragments are read two k-steps ahead of the MFMAs that consume them
@@ -382,12 +387,12 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
       bf16x8 d2 = d1;
       if (kk + 2 < 24) d2 = *reinterpret_cast<const bf16x8*>(brow + 32 * (kk + 2));
       if (kk < 16) {
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wrz[0][kk < 16 ? kk : 0], d0, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wrz[1][kk < 16 ? kk : 0], d0, acc[1], 0, 0, 0);
+        acc[0][kk & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wrz[0][kk < 16 ? kk : 0], d0, acc[0][kk & 1], 0, 0, 0);
+        acc[1][kk & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wrz[1][kk < 16 ? kk : 0], d0, acc[1][kk & 1], 0, 0, 0);
       } else {
         const bf16x8 w0 = wnp[(kk - 16) * 64], w1 = wnp[(8 + kk - 16) * 64];
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, d0, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, d0, acc[1], 0, 0, 0);
+        acc[0][kk & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, d0, acc[0][kk & 1], 0, 0, 0);
+        acc[1][kk & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, d0, acc[1][kk & 1], 0, 0, 0);
       }
       d0 = d1;
       d1 = d2;
@@ -395,7 +400,7 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dh[s][i] = acc[s][i];
+      for (int i = 0; i < 4; ++i) dh[s][i] = acc[s][0][i] + acc[s][1][i];
     __syncthreads();
   };
 

@@ -1,0 +1,54 @@
+"""Copy the rocprofv3 summaries of a gpurun session from gpurun_out/ (scratch) into profiles/ (tracked).
+usage: python tools/collect_profiles.py TAG [bench_json]"""
+import csv
+import json
+import shutil
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+tag = sys.argv[1]
+bench_json = Path(sys.argv[2]) if len(sys.argv) > 2 else None
+out = ROOT / "profiles"
+out.mkdir(exist_ok=True)
+src_prof = ROOT / "gpurun_out" / f"prof_{tag}"
+src_pmc = ROOT / "gpurun_out" / f"pmc_{tag}"
+
+stats = src_prof / "bench_kernel_stats.csv"
+if stats.exists():
+    rows = list(csv.DictReader(open(stats)))
+    keep = rows[:60] + [r for r in rows[60:] if "seld::" in r["Name"]]
+    with open(out / f"{tag}_bench_kernel_stats.csv", "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        for r in keep:
+            r = dict(r)
+            r["Name"] = r["Name"][:160]
+            w.writerow(r)
+    for name in ("bench_stdout.log",):
+        if (src_prof / name).exists():
+            text = [l for l in open(src_prof / name) if l.startswith("{")]
+            (out / f"{tag}_bench_under_rocprof.json").write_text("".join(text))
+if src_pmc.exists():
+    for p in sorted(src_pmc.glob("pass*.csv")):
+        shutil.copy(p, out / f"{tag}_pmc_logmel_{p.name}")
+if bench_json and bench_json.exists():
+    shutil.copy(bench_json, out / f"{tag}_bench.json")
+
+# traffic of the log-mel main kernel from the PMC passes (MI355X_MICROARCH.md, HBM section: FETCH_SIZE reads
+# half of a coalesced stream on gfx950 -> x2; WRITE_SIZE exact; both in KiB)
+summary = {}
+for p in sorted(src_pmc.glob("pass*.csv")) if src_pmc.exists() else []:
+    for r in csv.DictReader(open(p)):
+        if "logmel_main" in r["Kernel_Name"]:
+            summary[r["Counter_Name"]] = float(r["Counter_Value"])
+            summary.setdefault("dur_us", (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
+    clips = 32
+    summary["hbm_read_bytes_corrected"] = summary["FETCH_SIZE"] * 1024 * 2
+    summary["hbm_write_bytes"] = summary["WRITE_SIZE"] * 1024
+    summary["traffic_bytes_per_clip"] = (summary["hbm_read_bytes_corrected"] + summary["hbm_write_bytes"]) / clips
+    summary["algorithmic_bytes_per_clip"] = 26112896
+    (out / f"{tag}_pmc_logmel_summary.json").write_text(json.dumps(summary, indent=1))
+    print(json.dumps(summary, indent=1))
+print(sorted(p.name for p in out.iterdir()))
