@@ -58,6 +58,34 @@ int64_t seld_num_frames(int64_t L);
 int seld_logmel_f32(const float* pcm, int64_t N, int64_t C, int64_t L, float* out, int layout, void* stream);
 int seld_logmel_i16(const int16_t* pcm, int64_t N, int64_t C, int64_t L, float* out, int layout, void* stream);
 
+/* Same kernels with caller-defined output strides (elements): out[n*sN + c*sC + m*sM + t*sT] -- used to write
+ * the log-mel channels into a wider time-major feature tensor [N][F][C_total][64] next to the spatial features. */
+int seld_logmel_f32_strided(const float* pcm, int64_t N, int64_t C, int64_t L, float* out, int64_t sN, int64_t sC,
+                            int64_t sM, int64_t sT, void* stream);
+int seld_logmel_i16_strided(const int16_t* pcm, int64_t N, int64_t C, int64_t L, float* out, int64_t sN, int64_t sC,
+                            int64_t sM, int64_t sT, void* stream);
+
+/* ---- north-star additions without a reference implementation --------------
+ * The reference computes its STFT only implicitly inside torchaudio and has no intensity-vector / GCC-PHAT
+ * features; these entry points follow the DCASE SELD-baseline definitions.
+ *
+ * STFT (the complex spectrum the log-mel kernel squares): out_complex [N][C][F][481] complex64 (interleaved
+ * re, im; frame-major).  torch.stft(...) layout is its transpose(-1, -2). */
+int seld_stft_f32(const float* pcm, int64_t N, int64_t C, int64_t L, float* out_complex, void* stream);
+int seld_stft_i16(const int16_t* pcm, int64_t N, int64_t C, int64_t L, float* out_complex, void* stream);
+
+/* FOA intensity vectors from spectra [N][4][F][481] (channel 0 = W):
+ *   I_c[k] = Re(conj(W) X_c) / (1e-8 + |W|^2 + (|X_1|^2+|X_2|^2+|X_3|^2)/3),  iv[c][m] = sum_k fb[k][m] I_c[k]
+ * out[n*sN + c*sC + m*sM + t*sT], c = 0..2, m = 0..63. */
+int seld_foa_intensity(const float* spec_complex, int64_t N, int64_t F, float* out, int64_t sN, int64_t sC,
+                       int64_t sM, int64_t sT, void* stream);
+
+/* GCC-PHAT of all C(C-1)/2 channel pairs (m < n, lexicographic) from spectra [N][C][F][481], 2 <= C <= 8:
+ *   cc = irfft(R/|R|, 960) with R = conj(X_m) X_n;  out[n*sN + pair*sC + j*sM + t*sT] = cc[(j - 32) mod 960],
+ *   j = 0..63 (lags -32..31). */
+int seld_gcc_phat(const float* spec_complex, int64_t N, int64_t C, int64_t F, float* out, int64_t sN, int64_t sC,
+                  int64_t sM, int64_t sT, void* stream);
+
 /* ---- labels: dataset.py:60-119 metadata_to_labels + utils.py:77-90 polar_to_grid ---------- */
 /* events: int32 [R][5] = (meta_frame, class, source, azimuth_deg, elevation_deg), the CSV rows after
  * the reference's int() casts (dataset.py:93-97).  T = int((L/sr*1000)/20) label frames, computed by

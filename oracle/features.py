@@ -155,3 +155,30 @@ def pcm_to_int16(pcm: torch.Tensor) -> torch.Tensor:
 
 def int16_to_pcm(x: torch.Tensor) -> torch.Tensor:
     return x.to(torch.float32) / 32768.0
+
+
+# --------------------------------------------------------------------------- spatial features (A15 / A16)
+# The reference has NO intensity-vector / GCC-PHAT code (SURVEY.md F4): these are this project's own CPU
+# statements of the DCASE SELD-baseline definitions (DESIGN.md section 7).  Parity vs the reference: none possible.
+
+def foa_intensity_f64(pcm: np.ndarray, eps: float = 1e-8) -> np.ndarray:
+    """[4, L] (W first) -> [3, 64, F]: mel-projected, energy-normalised active intensity vectors."""
+    spec = stft_f64(pcm)                                            # [4, 481, F]
+    w, xyz = spec[0], spec[1:]
+    inten = np.real(np.conj(w)[None] * xyz)
+    energy = eps + np.abs(w) ** 2 + (np.abs(xyz) ** 2).sum(0) / 3.0
+    fb = mel_filterbank_htk().numpy().astype(np.float64)
+    return np.einsum("cft,fm->cmt", inten / energy[None], fb)
+
+
+def gcc_phat_f64(pcm: np.ndarray, n_lags: int = N_MELS) -> np.ndarray:
+    """[C, L] -> [C(C-1)/2, 64, F]: cc = irfft(exp(1j*angle(conj(X_m) X_n))), lags -32..31."""
+    spec = stft_f64(pcm)                                            # [C, 481, F]
+    c = spec.shape[0]
+    out = []
+    for m in range(c):
+        for n in range(m + 1, c):
+            r = np.conj(spec[m]) * spec[n]
+            cc = np.fft.irfft(np.exp(1j * np.angle(r)), n=N_FFT, axis=0)     # [960, F]
+            out.append(np.concatenate((cc[-n_lags // 2:], cc[:n_lags // 2]), axis=0))
+    return np.stack(out)

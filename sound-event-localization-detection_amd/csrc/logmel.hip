@@ -153,9 +153,97 @@ __global__ __launch_bounds__(kEdgeWaves * 64, 1) void logmel_edge_kernel(LogmelA
     if (tf + f < a.F) outp[f * a.sT] = db[f];
 }
 
+// ---- STFT export (north-star addition A14: the reference only has the STFT implicitly inside torchaudio).
+// Same stages A-C as the log-mel kernels; the un-packed complex spectra are written frame-major,
+// out[row][t][k] (complex64, 481 bins per frame).  One wavefront per run of iterations, generic load path
+// (reflection capable) for every iteration: this is an auxiliary API (it feeds the intensity-vector and
+// GCC-PHAT kernels), not the training hot loop.
+template <typename T>
+__global__ __launch_bounds__(kEdgeWaves * 64, 2) void stft_kernel(LogmelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int h = lane >> 5;
+  float* tab = smem;
+  float* lds = smem + kTabFloats + wave * kLdsFloatsPerWave;
+  fill_tables(a, tab, tid, kEdgeWaves * 64);
+  for (int i = lane; i < kLdsFloatsPerWave; i += 64) lds[i] = 0.0f;
+  __syncthreads();
+
+  const long total = a.rows * a.iters_per_row;
+  const long gw = static_cast<long>(blockIdx.x) * kEdgeWaves + wave;
+  const long begin = gw * a.chunk;
+  const long end = begin + a.chunk < total ? begin + a.chunk : total;
+  const T* pcm = static_cast<const T*>(a.pcm);
+#pragma unroll 1
+  for (long it = begin; it < end; ++it) {
+    const long row = it / a.iters_per_row;
+    const long itr = it - row * a.iters_per_row;
+    const long tf = itr * kFramesPerIter;
+    const bool interior = itr >= 1 && itr <= a.interior;
+    float s[48];
+    if (interior) load_samples<T, true>(lane, pcm + row * a.L, a.L, tf + 2 * h, s);
+    else load_samples<T, false>(lane, pcm + row * a.L, a.L, tf + 2 * h, s);
+    phase_a(lane, s, tab, lds);
+    SELD_WAVE_SYNC();
+    float zr[kN2], zi[kN2];
+    phase_b(lane, lds, zr, zi);
+    SELD_WAVE_SYNC();
+    phase_b_store(lane, lds, zr, zi);
+    SELD_WAVE_SYNC();
+    float mr[16], mi[16];
+    phase_c_load(lane, lds, mr, mi);
+    const long fa = tf + 2 * h;
+    float* base = a.out + (row * a.F + fa) * (2 * kBins);
+    phase_c_spectrum(lane, zr, zi, mr, mi, fa < a.F ? base : nullptr, fa + 1 < a.F ? base + 2 * kBins : nullptr);
+    SELD_WAVE_SYNC();
+  }
+}
+
+template <typename T>
+static int launch_stft(const T* pcm, int64_t N, int64_t C, int64_t L, float* out, hipStream_t stream) {
+  DeviceState* st = current_state();
+  if (!st) return kErrNotInitialised;
+  if (!pcm || !out) return fail(kErrInvalidArgument, "seld_stft: null pointer");
+  if (N <= 0 || C <= 0) return fail(kErrInvalidArgument, "seld_stft: N and C must be positive");
+  if (L <= kNfft / 2) return fail(kErrInvalidArgument, "seld_stft: reflect padding needs L > n_fft/2 = 480 samples");
+  if (L >= (1L << 30)) return fail(kErrUnsupported, "seld_stft: at most 2^30 samples per channel");
+  LogmelArgs a;
+  a.pcm = pcm;
+  a.out = out;
+  a.rows = N * C;
+  a.C = C;
+  a.L = L;
+  a.F = 1 + L / kHop;
+  a.iters_per_row = (a.F + kFramesPerIter - 1) / kFramesPerIter;
+  a.interior = (L / kHop - kFramesPerIter) / kFramesPerIter;
+  if (a.interior < 0) a.interior = 0;
+  if (a.interior > a.iters_per_row - 1) a.interior = a.iters_per_row - 1;
+  a.edge_per_row = a.iters_per_row - a.interior;
+  a.sN = a.sC = a.sM = a.sT = 0;
+  a.tab = st->tables();
+  const long total = a.rows * a.iters_per_row;
+  const long max_waves = static_cast<long>(st->num_cus) * 8;
+  long waves = (total + 3) / 4;
+  if (waves > max_waves) waves = max_waves;
+  a.chunk = (total + waves - 1) / waves;
+  const long used = (total + a.chunk - 1) / a.chunk;
+  static bool attr_done[2] = {false, false};
+  const int which = sizeof(T) == 4 ? 0 : 1;
+  if (!attr_done[which]) {
+    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(stft_kernel<T>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kEdgeLdsBytes));
+    attr_done[which] = true;
+  }
+  hipLaunchKernelGGL(stft_kernel<T>, dim3(static_cast<unsigned>((used + kEdgeWaves - 1) / kEdgeWaves)),
+                     dim3(kEdgeWaves * 64), kEdgeLdsBytes, stream, a);
+  SELD_HIP_TRY(hipGetLastError());
+  return kOk;
+}
+
 template <typename T>
 static int launch_logmel(const T* pcm, int64_t N, int64_t C, int64_t L, float* out, int layout,
-                         hipStream_t stream) {
+                         hipStream_t stream, const int64_t* strides = nullptr) {
   DeviceState* st = current_state();
   if (!st) return kErrNotInitialised;
   if (!pcm || !out) return fail(kErrInvalidArgument, "seld_logmel: null pointer");
@@ -163,7 +251,7 @@ static int launch_logmel(const T* pcm, int64_t N, int64_t C, int64_t L, float* o
   if (L <= kNfft / 2)
     return fail(kErrInvalidArgument, "seld_logmel: reflect padding needs L > n_fft/2 = 480 samples");
   if (L >= (1L << 30)) return fail(kErrUnsupported, "seld_logmel: at most 2^30 samples per channel");
-  if (layout != 0 && layout != 1) return fail(kErrInvalidArgument, "seld_logmel: layout must be 0 or 1");
+  if (!strides && layout != 0 && layout != 1) return fail(kErrInvalidArgument, "seld_logmel: layout must be 0 or 1");
 
   LogmelArgs a;
   a.pcm = pcm;
@@ -178,7 +266,12 @@ static int launch_logmel(const T* pcm, int64_t N, int64_t C, int64_t L, float* o
   if (a.interior < 0) a.interior = 0;
   if (a.interior > a.iters_per_row - 1) a.interior = a.iters_per_row - 1;
   a.edge_per_row = a.iters_per_row - a.interior;
-  if (layout == 0) {            // [N, C, 64, F]  (reference layout, dataset.py:53)
+  if (strides) {                // caller-defined placement (e.g. channels 0..C-1 of a wider feature tensor)
+    a.sN = strides[0];
+    a.sC = strides[1];
+    a.sM = strides[2];
+    a.sT = strides[3];
+  } else if (layout == 0) {     // [N, C, 64, F]  (reference layout, dataset.py:53)
     a.sT = 1;
     a.sM = a.F;
     a.sC = kMels * a.F;
@@ -242,6 +335,26 @@ int seld_logmel_f32(const float* pcm, int64_t N, int64_t C, int64_t L, float* ou
 
 int seld_logmel_i16(const int16_t* pcm, int64_t N, int64_t C, int64_t L, float* out, int layout, void* stream) {
   return seld::launch_logmel<int16_t>(pcm, N, C, L, out, layout, static_cast<hipStream_t>(stream));
+}
+
+int seld_logmel_f32_strided(const float* pcm, int64_t N, int64_t C, int64_t L, float* out, int64_t sN, int64_t sC,
+                            int64_t sM, int64_t sT, void* stream) {
+  const int64_t strides[4] = {sN, sC, sM, sT};
+  return seld::launch_logmel<float>(pcm, N, C, L, out, 0, static_cast<hipStream_t>(stream), strides);
+}
+
+int seld_logmel_i16_strided(const int16_t* pcm, int64_t N, int64_t C, int64_t L, float* out, int64_t sN, int64_t sC,
+                            int64_t sM, int64_t sT, void* stream) {
+  const int64_t strides[4] = {sN, sC, sM, sT};
+  return seld::launch_logmel<int16_t>(pcm, N, C, L, out, 0, static_cast<hipStream_t>(stream), strides);
+}
+
+int seld_stft_f32(const float* pcm, int64_t N, int64_t C, int64_t L, float* out_complex, void* stream) {
+  return seld::launch_stft<float>(pcm, N, C, L, out_complex, static_cast<hipStream_t>(stream));
+}
+
+int seld_stft_i16(const int16_t* pcm, int64_t N, int64_t C, int64_t L, float* out_complex, void* stream) {
+  return seld::launch_stft<int16_t>(pcm, N, C, L, out_complex, static_cast<hipStream_t>(stream));
 }
 
 int64_t seld_num_frames(int64_t L) { return 1 + L / seld::kHop; }

@@ -124,34 +124,17 @@ SELD_HD void load_samples(int lane, const T* row, long L, long fa, float (&s)[48
   }
 }
 
-// NOTE on addressing: every LDS access below is written as  (one per-lane base pointer)[compile-time
-// constant]  so that it becomes a single base VGPR plus the DS instruction's immediate offset.  Spelling
-// the index as one expression makes the compiler hoist a separate loop-invariant address register for
-// every distinct constant (dozens of VGPRs, which then spill).
-
-// ---- Phase A: window, pack two frames, 32-pt DFT, twiddle, LDS column store.
-SELD_HD void phase_a(int lane, const float (&s)[48], const float* tab, float* lds) {
+// Tail of stage A: multiply the 32-pt DFT outputs by the two-level twiddles W_960^{n2*k1} = hi[k1>>3]*lo[k1&7]
+// (`tw_lane` = this lane's quad in the twiddle table rows: [5][64][4] floats, row v at +256 v) and store
+// column l of this half-wavefront's [32][31]-complex exchange tile.
+SELD_HD void stage_a_finish(int lane, const float (&re)[kN1], const float (&im)[kN1], const float* tw_lane, float* lds) {
   const int h = lane >> 5;
   const int l = lane & 31;
-  const float* tl = tab + lane * 4;                    // this lane's quad in every table row
-  float re[kN1], im[kN1];
-#pragma unroll
-  for (int qd = 0; qd < 8; ++qd) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n1 = 4 * qd + j;
-      const float w = tl[kTabWin + qd * 256 + j];        // 0.5 * Hann (see table_value)
-      re[n1] = w * s[n1];            // frame fa
-      im[n1] = w * s[n1 + 16];       // frame fa+1 = same samples shifted by 480 = 16*30
-    }
-  }
-  dft32(re, im);
-  // two-level twiddles W_960^{n2*k1} = hi[k1>>3] * lo[k1&7]
   float tw[20];
 #pragma unroll
   for (int v = 0; v < 5; ++v)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) tw[4 * v + j] = tl[kTabTw + v * 256 + j];
+    for (int j = 0; j < 4; ++j) tw[4 * v + j] = tw_lane[v * 256 + j];
   if (l < kN2) {
     float* e = lds + e_index(h, 0, l);                 // column l of this half's tile; row k1 is at +62*k1
 #pragma unroll
@@ -174,6 +157,31 @@ SELD_HD void phase_a(int lane, const float (&s)[48], const float* tab, float* ld
       e[k1 * kEPitch * 2 + 1] = yi;
     }
   }
+}
+
+// NOTE on addressing: every LDS access below is written as  (one per-lane base pointer)[compile-time
+// constant]  so that it becomes a single base VGPR plus the DS instruction's immediate offset.  Spelling
+// the index as one expression makes the compiler hoist a separate loop-invariant address register for
+// every distinct constant (dozens of VGPRs, which then spill).
+
+// ---- Phase A: window, pack two frames, 32-pt DFT, twiddle, LDS column store.
+SELD_HD void phase_a(int lane, const float (&s)[48], const float* tab, float* lds) {
+  const int h = lane >> 5;
+  const int l = lane & 31;
+  const float* tl = tab + lane * 4;                    // this lane's quad in every table row
+  float re[kN1], im[kN1];
+#pragma unroll
+  for (int qd = 0; qd < 8; ++qd) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n1 = 4 * qd + j;
+      const float w = tl[kTabWin + qd * 256 + j];        // 0.5 * Hann (see table_value)
+      re[n1] = w * s[n1];            // frame fa
+      im[n1] = w * s[n1 + 16];       // frame fa+1 = same samples shifted by 480 = 16*30
+    }
+  }
+  dft32(re, im);
+  stage_a_finish(lane, re, im, tl + kTabTw, lds);
 }
 
 // ---- Phase B: 30-pt DFT along n2 for row k1 = l, then park the upper half-spectrum for the mirror read.
@@ -233,6 +241,29 @@ SELD_HD void phase_c_store(int lane, float* lds, const float (&zr)[kN2], const f
       const float br = zi[r] + mi[r], bi = zr[r] - mr[r];
       p[32 * r] = ar * ar + ai * ai;
       p[kPPitch + 32 * r] = br * br + bi * bi;
+    }
+  }
+}
+
+// Variant of phase C for the STFT export: the un-packed complex spectra of the two frames go straight to
+// global memory (frame-major rows of 481 complex: 32 lanes x 8 B = one 256-B run per store).
+//   Xa = (ar, ai) ,  Xb = (br, -bi)   with the quantities of phase_c_store (the 1/2 is in the window table)
+SELD_HD void phase_c_spectrum(int lane, const float (&zr)[kN2], const float (&zi)[kN2], const float (&mr)[16],
+                              const float (&mi)[16], float* row_a, float* row_b) {
+  const int l = lane & 31;
+  float* pa = row_a ? row_a + 2 * l : nullptr;        // complex bin l + 32 r is at +64 r floats
+  float* pb = row_b ? row_b + 2 * l : nullptr;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (r < 15 || l == 0) {
+      if (pa) {
+        pa[64 * r] = zr[r] + mr[r];
+        pa[64 * r + 1] = zi[r] - mi[r];
+      }
+      if (pb) {
+        pb[64 * r] = zi[r] + mi[r];
+        pb[64 * r + 1] = mr[r] - zr[r];
+      }
     }
   }
 }

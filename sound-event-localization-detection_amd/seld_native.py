@@ -48,6 +48,12 @@ def _declare(lib):
     lib.seld_num_frames.argtypes = [_i64]
     for name in ("seld_logmel_f32", "seld_logmel_i16"):
         getattr(lib, name).argtypes = [_ptr, _i64, _i64, _i64, _ptr, _int, _ptr]
+    for name in ("seld_logmel_f32_strided", "seld_logmel_i16_strided"):
+        getattr(lib, name).argtypes = [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr]
+    for name in ("seld_stft_f32", "seld_stft_i16"):
+        getattr(lib, name).argtypes = [_ptr, _i64, _i64, _i64, _ptr, _ptr]
+    lib.seld_foa_intensity.argtypes = [_ptr, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr]
+    lib.seld_gcc_phat.argtypes = [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr]
     lib.seld_labels_rasterise.argtypes = [_ptr, _i64, _i64, _int, _int, _ptr, _ptr]
     lib.seld_labels_expand.argtypes = [_ptr, _i64, _int, _ptr, _ptr]
     lib.seld_window_gather.argtypes = [_ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr]
@@ -331,3 +337,67 @@ def gru_backward(dy: torch.Tensor, saved: torch.Tensor, w_hh: torch.Tensor) -> t
         check(load_library().seld_gru_backward(_p(dy_tile), _p(saved), int(dy.dtype == torch.bfloat16), _p(w_t),
                                                tiles, t, h, _p(dg_tile), _stream_ptr(dy.device)), "seld_gru_backward")
     return from_tile(dg_tile, b)
+
+
+# --------------------------------------------------------------------------- STFT / spatial features
+
+def _prep_pcm(pcm):
+    squeeze = pcm.dim() == 2
+    if squeeze:
+        pcm = pcm.unsqueeze(0)
+    if pcm.dim() != 3 or not pcm.is_cuda or pcm.dtype not in (torch.float32, torch.int16):
+        raise SeldNativeError("pcm must be a GPU tensor [N, C, L] (or [C, L]) of float32 or int16")
+    return pcm.contiguous(), squeeze
+
+
+def stft(pcm: torch.Tensor) -> torch.Tensor:
+    """Complex STFT (960 / 480 / periodic Hann / center, reflect): [N, C, L] -> complex64 [N, C, F, 481]
+    (frame-major; ``.transpose(-1, -2)`` gives torch.stft's [.., 481, F])."""
+    pcm, squeeze = _prep_pcm(pcm)
+    n, c, length = pcm.shape
+    index = ensure_init(pcm.device)
+    out = torch.empty((n, c, num_frames(length), N_BINS, 2), dtype=torch.float32, device=pcm.device)
+    fn = load_library().seld_stft_f32 if pcm.dtype == torch.float32 else load_library().seld_stft_i16
+    with torch.cuda.device(index):
+        check(fn(_p(pcm), n, c, length, _p(out), _stream_ptr(pcm.device)), "seld_stft")
+    spec = torch.view_as_complex(out)
+    return spec[0] if squeeze else spec
+
+
+def spatial_features(pcm: torch.Tensor, kind: str) -> torch.Tensor:
+    """Time-major feature tensor [N, F, C_total, 64] (float32) for one of
+      'logmel'      C_total = C                       (the reference's features)
+      'logmel_iv'   C_total = 4 + 3   (FOA: log-mel + mel-projected intensity vectors; needs C = 4)
+      'logmel_gcc'  C_total = C + C(C-1)/2            (MIC: log-mel + GCC-PHAT, 2 <= C <= 8)."""
+    pcm, squeeze = _prep_pcm(pcm)
+    n, c, length = pcm.shape
+    frames = num_frames(length)
+    if kind == "logmel":
+        out = logmel(pcm, layout="tcf")
+        return out[0] if squeeze else out
+    if kind == "logmel_iv":
+        if c != 4:
+            raise ValueError("FOA intensity vectors need 4 channels (W first)")
+        extra = 3
+    elif kind == "logmel_gcc":
+        if not 2 <= c <= 8:
+            raise ValueError("GCC-PHAT supports 2..8 channels")
+        extra = c * (c - 1) // 2
+    else:
+        raise ValueError(f"unknown feature kind {kind!r}")
+    index = ensure_init(pcm.device)
+    total = c + extra
+    out = torch.empty((n, frames, total, N_MELS), dtype=torch.float32, device=pcm.device)
+    s_n, s_t, s_c, s_m = frames * total * N_MELS, total * N_MELS, N_MELS, 1
+    lib = load_library()
+    stream = _stream_ptr(pcm.device)
+    with torch.cuda.device(index):
+        fn = lib.seld_logmel_f32_strided if pcm.dtype == torch.float32 else lib.seld_logmel_i16_strided
+        check(fn(_p(pcm), n, c, length, _p(out), s_n, s_c, s_m, s_t, stream), "seld_logmel_strided")
+        spec = torch.view_as_real(stft(pcm))                                  # [N, C, F, 481, 2]
+        tail = ctypes.c_void_p(out.data_ptr() + c * N_MELS * 4)              # channel offset c
+        if kind == "logmel_iv":
+            check(lib.seld_foa_intensity(_p(spec), n, frames, tail, s_n, s_c, s_m, s_t, stream), "seld_foa_intensity")
+        else:
+            check(lib.seld_gcc_phat(_p(spec), n, c, frames, tail, s_n, s_c, s_m, s_t, stream), "seld_gcc_phat")
+    return out[0] if squeeze else out

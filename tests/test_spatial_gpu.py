@@ -1,0 +1,68 @@
+"""GPU tests of the north-star feature additions that have NO reference implementation (SURVEY.md F4, section 8
+A14-A16): explicit STFT, FOA intensity vectors, GCC-PHAT.  The oracle is this project's own float64 statement
+of the DCASE SELD-baseline definitions (oracle/features.py) -- parity with the reference is not claimable."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import features as ofeat
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("num_samples", [481, 4800, 24123])
+def test_stft_matches_torch_stft(gpu_device, num_samples):
+    import seld_native
+    pcm = ofeat.synth_pcm(3, 4, num_samples, "noise")
+    got = seld_native.stft(pcm.to(gpu_device)).cpu()                      # [4, F, 481]
+    ref = ofeat.stft_torch(pcm).transpose(-1, -2)                         # [4, F, 481]
+    assert tuple(got.shape) == tuple(ref.shape) == (4, 1 + num_samples // 480, 481)
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 2e-6 * scale
+    ref64 = np.swapaxes(ofeat.stft_f64(pcm.numpy()), -1, -2)
+    assert np.abs(got.numpy() - ref64).max() <= 2e-6 * scale
+    # the log-mel kernel squares exactly this spectrum
+    mel = torch.einsum("cfk,km->cmf", got.abs() ** 2, ofeat.mel_filterbank_htk())
+    db = 10 * torch.log10(mel.clamp(min=1e-10))
+    assert (db - seld_native.logmel(pcm.to(gpu_device)).cpu()).abs().max().item() <= 1e-4
+
+
+def test_foa_intensity_vectors(gpu_device):
+    import seld_native
+    pcm = ofeat.synth_pcm(4, 4, 24000, "noise")
+    pcm[1] = 0.7 * pcm[0] + 0.3 * pcm[1]                                  # correlate X with W: non-trivial vectors
+    feat = seld_native.spatial_features(pcm.to(gpu_device), "logmel_iv").cpu()      # [F, 7, 64]
+    assert tuple(feat.shape) == (51, 7, 64)
+    assert (feat[:, :4].permute(1, 2, 0) - ofeat.logmel_torch(pcm)).abs().max().item() <= 1e-4
+    ref = ofeat.foa_intensity_f64(pcm.numpy())                            # [3, 64, F]
+    got = feat[:, 4:].permute(1, 2, 0).numpy()
+    assert np.abs(got - ref).max() <= 1e-4                                # values are O(1) per mel band
+    assert np.abs(ref[0]).max() > 0.1                                     # the planted correlation shows up
+
+
+@pytest.mark.parametrize("channels", [8, 4, 2])
+def test_gcc_phat(gpu_device, channels):
+    import seld_native
+    pcm = ofeat.synth_pcm(6, channels, 12000 + 17, "noise")
+    pcm[1, 7:] = pcm[0, :-7]                                              # channel 1 = channel 0 delayed by 7 samples
+    feat = seld_native.spatial_features(pcm.to(gpu_device), "logmel_gcc").cpu()
+    pairs = channels * (channels - 1) // 2
+    frames = 1 + pcm.shape[1] // 480
+    assert tuple(feat.shape) == (frames, channels + pairs, 64)
+    assert (feat[:, :channels].permute(1, 2, 0) - ofeat.logmel_torch(pcm)).abs().max().item() <= 1e-4
+    ref = ofeat.gcc_phat_f64(pcm.numpy())                                 # [pairs, 64, F]
+    got = feat[:, channels:].permute(1, 2, 0).numpy()
+    assert np.abs(got - ref).max() <= 1e-4
+    # pair (0, 1): the peak sits at lag +7 (index 32 + 7) in the interior frames
+    assert (got[0, :, 3:-3].argmax(axis=0) == 39).all()
+
+
+def test_batched_spatial_features(gpu_device):
+    import seld_native
+    pcm = torch.stack([ofeat.synth_pcm(i, 4, 9600, "noise") for i in range(3)]).to(gpu_device)
+    iv = seld_native.spatial_features(pcm, "logmel_iv")
+    gcc = seld_native.spatial_features(pcm, "logmel_gcc")
+    assert tuple(iv.shape) == (3, 21, 7, 64) and tuple(gcc.shape) == (3, 21, 10, 64)
+    for i in range(3):
+        assert torch.equal(iv[i], seld_native.spatial_features(pcm[i], "logmel_iv"))
+        assert torch.equal(gcc[i], seld_native.spatial_features(pcm[i], "logmel_gcc"))
