@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from oracle import features as ofeat
+from logmel_checks import assert_logmel_close
 
 pytestmark = pytest.mark.gpu
 
@@ -26,8 +27,7 @@ def test_noise_matches_oracle(gpu_device, num_samples):
     got = _gpu_logmel(pcm, gpu_device)
     ref = ofeat.logmel_torch(pcm)
     assert got.shape == ref.shape == (4, 64, 1 + num_samples // 480)
-    assert torch.isfinite(got).all()
-    assert (got - ref).abs().max().item() <= TOL_DB
+    assert_logmel_close(got.numpy(), ref.numpy())
 
 
 def test_reference_recorded_frame_count(gpu_device):
@@ -44,7 +44,7 @@ def test_golden_int16_vector(gpu_device, golden_dir):
     z = np.load(golden_dir / "logmel_noise_1s.npz")
     pcm = torch.from_numpy(z["pcm_i16"])
     got = _gpu_logmel(pcm, gpu_device)                       # int16 entry point
-    assert (got - torch.from_numpy(z["logmel_from_i16"])).abs().max().item() <= TOL_DB
+    assert_logmel_close(got.numpy(), z["logmel_from_i16"])
     got_f = _gpu_logmel(ofeat.int16_to_pcm(pcm), gpu_device)  # same samples through the f32 entry point
     # same arithmetic, but the compiler may contract mul+add into fma differently in the two instantiations
     assert (got - got_f).abs().max().item() <= 2e-5
@@ -64,7 +64,7 @@ def test_batched_equals_per_clip_and_channels(gpu_device):
     batched = seld_native.logmel(pcm.to(gpu_device)).cpu()
     for i in range(3):
         assert torch.equal(batched[i], _gpu_logmel(pcm[i], gpu_device))
-    assert (batched[1] - ofeat.logmel_torch(pcm[1])).abs().max().item() <= TOL_DB
+    assert_logmel_close(batched[1].numpy(), ofeat.logmel_torch(pcm[1]).numpy())
 
 
 def test_tones_and_silence_against_float64(gpu_device):
@@ -115,8 +115,12 @@ def test_full_size_properties_60s_clip(gpu_device):
     a_host = a.cpu()
     for t in frames[:50]:
         seg = host[:, 480 * (t - 2): 480 * (t + 3)]                # frames t-1..t+1 fully inside
-        ref = ofeat.logmel_torch(seg)[:, :, 2]
-        assert (a_host[:, :, t] - ref).abs().max().item() <= TOL_DB
+        ref = ofeat.logmel_torch(seg)[:, :, 2:3]
+        assert_logmel_close(a_host[:, :, t:t + 1].numpy(), ref.numpy())
+    # and the whole 60 s clip against the oracle (the bar of logmel_checks: 1e-4 dB on every band within 40 dB
+    # of its frame's peak, fp32-noise-floor bound below that)
+    worst, weak_share = assert_logmel_close(a_host.numpy(), ofeat.logmel_torch(host).numpy())
+    assert weak_share < 1e-3
 
 
 def test_rejects_bad_arguments(gpu_device):
