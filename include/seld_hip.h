@@ -96,6 +96,13 @@ int seld_gcc_phat(const float* spec_complex, int64_t N, int64_t C, int64_t F, fl
  * IndexError for class >= 14 -- the Python host checks that before upload).  I*J must be even. */
 int seld_labels_rasterise(const int32_t* events, int64_t R, int64_t T, int I, int J, uint16_t* mask, void* stream);
 
+/* Gaussian-region label augmentation, smrl_seld_gaussian.py:397-534 (active there, absent from the modular
+ * dataset.py).  Like seld_labels_rasterise, but every row paints its class into all cells whose centre lies in the
+ * +-2 sigma box around centres[r] = (azimuth + az_noise, elevation + el_noise) (float64, degrees; the per-source
+ * noise is drawn on the host, :426-437); azimuth wraps, elevation is clipped to [-90, 90]. */
+int seld_labels_rasterise_box(const int32_t* events, const double* centres, int64_t R, int64_t T, int I, int J,
+                              double sigma_az, double sigma_el, uint16_t* mask, void* stream);
+
 /* mask uint16 [n_cells] -> dense float32 [n_cells][num_classes] exactly as dataset.py:110-117 leaves it. */
 int seld_labels_expand(const uint16_t* mask, int64_t n_cells, int num_classes, float* dense, void* stream);
 

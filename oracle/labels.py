@@ -131,3 +131,78 @@ def synth_metadata(clip_idx: int, meta_frames: int = 600, seed_base: int = 1234)
 
 def metadata_to_csv(rows: np.ndarray) -> str:
     return "".join(",".join(str(int(v)) for v in r) + "\n" for r in rows)
+
+
+# --------------------------------------------------------------------------- Gaussian-region augmentation
+
+def gaussian_source_noise(rows: np.ndarray, sigma_az: float = 5.0, sigma_el: float = 5.0, rng=None) -> np.ndarray:
+    """smrl_seld_gaussian.py:426-437: one (az, el) normal draw per unique (class, source), in the sorted key
+    order of ``df.groupby([1, 2])``; returns the box centre (az + noise, el + noise) of every row."""
+    rng = np.random if rng is None else rng
+    keys = sorted({(int(r[1]), int(r[2])) for r in rows})
+    noise = {}
+    for k in keys:
+        noise[k] = (rng.normal(0, sigma_az), rng.normal(0, sigma_el))
+    return np.asarray([(r[3] + noise[(int(r[1]), int(r[2]))][0], r[4] + noise[(int(r[1]), int(r[2]))][1])
+                       for r in rows], dtype=np.float64).reshape(-1, 2)
+
+
+def gaussian_labels_loops(rows: np.ndarray, centres: np.ndarray, num_samples: int, sample_rate: int = 24000,
+                          I: int = GRID_I, J: int = GRID_J, num_classes: int = NUM_CLASSES,
+                          sigma_azimuth: float = 5.0, sigma_elevation: float = 5.0) -> np.ndarray:
+    """Line-for-line restatement of smrl_seld_gaussian.py:440-532 given the per-row box centres."""
+    total_frames = total_label_frames(num_samples, sample_rate)
+    labels = np.zeros((total_frames, I * J, num_classes), dtype=np.float32)
+    active = [set() for _ in range(total_frames)]
+    for row, (center_azimuth, center_elevation) in zip(rows, centres):
+        metadata_frame, active_class = int(row[0]), int(row[1])
+        start_frame = metadata_frame * FRAMES_PER_META
+        end_frame = min(start_frame + FRAMES_PER_META, total_frames)
+        elevation_min = max(center_elevation - 2 * sigma_elevation, -90)
+        elevation_max = min(center_elevation + 2 * sigma_elevation, 90)
+        affected = set()
+        for grid_i in range(I):
+            for grid_j in range(J):
+                cell_elevation = -90 + (grid_i + 0.5) * (180.0 / I)
+                cell_azimuth = -180 + (grid_j + 0.5) * (360.0 / J)
+                diff = cell_azimuth - center_azimuth
+                while diff > 180:
+                    diff -= 360
+                while diff < -180:
+                    diff += 360
+                if abs(diff) <= 2 * sigma_azimuth and elevation_min <= cell_elevation <= elevation_max:
+                    affected.add(grid_i * J + grid_j)
+        for cell_idx in affected:
+            for t in range(start_frame, end_frame):
+                labels[t, cell_idx, active_class] = 1.0
+                active[t].add(cell_idx)
+    for t in range(total_frames):
+        for cell_idx in range(I * J):
+            if cell_idx not in active[t]:
+                labels[t, cell_idx, num_classes - 1] = 1.0
+    return labels
+
+
+def gaussian_mask(rows: np.ndarray, centres: np.ndarray, num_samples: int, sample_rate: int = 24000,
+                  I: int = GRID_I, J: int = GRID_J, sigma_azimuth: float = 5.0, sigma_elevation: float = 5.0) -> np.ndarray:
+    """Vectorised uint16 form of ``gaussian_labels_loops`` (same float64 comparisons, whole grid at once);
+    used for the sizes the loops cannot finish in seconds."""
+    total_frames = total_label_frames(num_samples, sample_rate)
+    mask = np.zeros((total_frames, I * J), dtype=np.uint16)
+    cell_el = -90 + (np.arange(I, dtype=np.float64) + 0.5) * (180.0 / I)
+    cell_az = -180 + (np.arange(J, dtype=np.float64) + 0.5) * (360.0 / J)
+    for row, (c_az, c_el) in zip(rows, np.asarray(centres, dtype=np.float64).reshape(-1, 2)):
+        start = int(row[0]) * FRAMES_PER_META
+        end = min(start + FRAMES_PER_META, total_frames)
+        if start >= end:
+            continue
+        diff = cell_az - c_az
+        for _ in range(4):                                  # the two while loops of :498-505 (|diff| < 4*360 here)
+            diff = np.where(diff > 180, diff - 360, diff)
+        for _ in range(4):
+            diff = np.where(diff < -180, diff + 360, diff)
+        az_ok = np.abs(diff) <= 2 * sigma_azimuth
+        el_ok = (max(c_el - 2 * sigma_elevation, -90) <= cell_el) & (cell_el <= min(c_el + 2 * sigma_elevation, 90))
+        box = (el_ok[:, None] & az_ok[None, :]).reshape(-1)
+        mask[start:end, box] |= np.uint16(1 << int(row[1]))
+    return mask

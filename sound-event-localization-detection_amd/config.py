@@ -95,6 +95,9 @@ class Config:
     DDP_BUCKET_MB = 25          # RCCL all-reduce bucket size
     SYNC_BATCHNORM = False      # per-rank BN statistics by default
     SEED = None                 # the reference never seeds; set an int for reproducible runs
+    GAUSSIAN_AUGMENT = False    # smrl_seld_gaussian.py:397-534 label augmentation (+-2 sigma box per source)
+    GAUSSIAN_SIGMA_AZIMUTH = 5.0
+    GAUSSIAN_SIGMA_ELEVATION = 5.0
 
     def __init__(self):
         for folder in (self.OUTPUT_PATH, self.CHECKPOINT_PATH):

@@ -45,6 +45,47 @@ __global__ void rasterise_kernel(const int32_t* __restrict__ ev, long R, long T,
   atomicOr(mask_words + (idx >> 1), bit);
 }
 
+// Gaussian-region label augmentation (smrl_seld_gaussian.py:397-534): every event paints the class bit into ALL
+// grid cells whose centre lies inside the +-2 sigma box around (azimuth + az_noise, elevation + el_noise), with
+// azimuth wrap-around and elevation clipped to [-90, 90].  The per-source noise is drawn on the host (one
+// (az, el) normal pair per unique (class, source), :426-437) and arrives as the box centre of every row.
+// One thread per (row, cell); float64 and the reference's comparison order, so the painted set is bit-exact.
+__global__ void rasterise_box_kernel(const int32_t* __restrict__ ev, const double* __restrict__ centre, long R, long T,
+                                     int I, int J, double two_sigma_az, double two_sigma_el,
+                                     unsigned int* __restrict__ mask_words) {
+  const long cells = static_cast<long>(I) * J;
+  const long gid = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (gid >= R * cells) return;
+  const long r = gid / cells;
+  const int cell = static_cast<int>(gid - r * cells);
+  const int32_t* row = ev + r * 5;
+  const long meta_frame = row[0];
+  const int cls = row[1];
+  if (meta_frame < 0 || cls < 0 || cls > 15) return;
+  const long start = meta_frame * kFramesPerMeta;
+  long end = start + kFramesPerMeta;
+  if (end > T) end = T;
+  if (start >= end) return;
+  const int gi = cell / J, gj = cell - gi * J;
+  const double centre_az = centre[2 * r], centre_el = centre[2 * r + 1];
+  double el_min = centre_el - two_sigma_el, el_max = centre_el + two_sigma_el;
+  el_min = el_min > -90.0 ? el_min : -90.0;                 // max(elevation_min, -90)
+  el_max = el_max < 90.0 ? el_max : 90.0;                   // min(elevation_max, 90)
+  // __dmul_rn / __dadd_rn: separately rounded like CPython's float ops (no fma contraction)
+  const double cell_el = __dadd_rn(-90.0, __dmul_rn(gi + 0.5, 180.0 / I));
+  const double cell_az = __dadd_rn(-180.0, __dmul_rn(gj + 0.5, 360.0 / J));
+  double diff = cell_az - centre_az;                        // normalize_azimuth_diff (:498-505)
+  while (diff > 180.0) diff -= 360.0;
+  while (diff < -180.0) diff += 360.0;
+  const bool az_ok = fabs(diff) <= two_sigma_az;
+  const bool el_ok = el_min <= cell_el && cell_el <= el_max;
+  if (!(az_ok && el_ok)) return;
+  for (long t = start; t < end; ++t) {
+    const long idx = t * cells + cell;
+    atomicOr(mask_words + (idx >> 1), (1u << cls) << ((idx & 1) * 16));
+  }
+}
+
 // mask -> dense float32 [n][M]: bit c -> 1.0; background (class M-1) = 1.0 where mask == 0.
 // Each thread writes one float4 (n*M is a multiple of 4 because the grid has an even cell count).
 __global__ void expand_kernel(const uint16_t* __restrict__ mask, long n_cells, int M, float4* __restrict__ dense) {
@@ -112,6 +153,27 @@ int seld_labels_rasterise(const int32_t* events, int64_t R, int64_t T, int I, in
   const unsigned blocks = static_cast<unsigned>((threads + 255) / 256);
   hipLaunchKernelGGL(rasterise_kernel, dim3(blocks), dim3(256), 0, stream, events, static_cast<long>(R),
                      static_cast<long>(T), I, J, reinterpret_cast<unsigned int*>(mask));
+  SELD_HIP_TRY(hipGetLastError());
+  return kOk;
+}
+
+int seld_labels_rasterise_box(const int32_t* events, const double* centres, int64_t R, int64_t T, int I, int J,
+                              double sigma_az, double sigma_el, uint16_t* mask, void* stream_) {
+  using namespace seld;
+  DeviceState* st = current_state();
+  if (!st) return kErrNotInitialised;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (T < 0 || R < 0 || I <= 0 || J <= 0) return fail(kErrInvalidArgument, "seld_labels_rasterise_box: bad extents");
+  if ((static_cast<long>(I) * J) % 2 != 0)
+    return fail(kErrUnsupported, "seld_labels_rasterise_box: I*J must be even");
+  if (T == 0) return kOk;
+  if (!mask || (R > 0 && (!events || !centres))) return fail(kErrInvalidArgument, "seld_labels_rasterise_box: null pointer");
+  SELD_HIP_TRY(hipMemsetAsync(mask, 0, static_cast<size_t>(T) * I * J * sizeof(uint16_t), stream));
+  if (R == 0) return kOk;
+  const long threads = R * I * J;
+  hipLaunchKernelGGL(rasterise_box_kernel, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, stream,
+                     events, centres, static_cast<long>(R), static_cast<long>(T), I, J, 2.0 * sigma_az, 2.0 * sigma_el,
+                     reinterpret_cast<unsigned int*>(mask));
   SELD_HIP_TRY(hipGetLastError());
   return kOk;
 }

@@ -141,6 +141,29 @@ def metadata_to_labels(metadata_path, audio_duration, sample_rate=24000, I=None,
     return seld_native.expand_labels(mask, num_classes).cpu(), I, J
 
 
+def augment_with_gaussian_mask(metadata_path, audio_duration, I=None, J=None, cell_size_deg=None,
+                               sigma_azimuth=5.0, sigma_elevation=5.0, device=None, rng=None):
+    """Compact form of ``augment_with_gaussian_noise``: uint16 [T, I*J] on the GPU.  The per-source normal
+    draws (smrl_seld_gaussian.py:426-437) come from ``rng`` (default ``numpy.random`` like the reference)."""
+    cell_size_deg = config.GRID_CELL_DEGREES if cell_size_deg is None else cell_size_deg
+    I, J = _grid_dims(I, J, cell_size_deg)
+    rows = _read_metadata_rows(metadata_path) if not isinstance(metadata_path, np.ndarray) else metadata_path
+    total_frames = label_frame_count(audio_duration)
+    device = _compute_device() if device is None else device
+    centres = seld_native.gaussian_source_noise(rows, sigma_azimuth, sigma_elevation, rng=rng)
+    return seld_native.rasterise_labels_gaussian(torch.from_numpy(np.ascontiguousarray(rows)), centres, total_frames,
+                                                 I, J, sigma_azimuth, sigma_elevation, device=device), I, J
+
+
+def augment_with_gaussian_noise(metadata_path, audio_duration, sample_rate=24000, I=None, J=None,
+                                cell_size_deg=None, num_classes=14, sigma_azimuth=5.0, sigma_elevation=5.0, rng=None):
+    """smrl_seld_gaussian.py:397-534 with the same signature and return value: every source paints its class
+    into all grid cells whose centre lies in the +-2 sigma box around its (noise-shifted) direction."""
+    mask, I, J = augment_with_gaussian_mask(metadata_path, audio_duration, I, J, cell_size_deg, sigma_azimuth,
+                                            sigma_elevation, rng=rng)
+    return seld_native.expand_labels(mask, num_classes).cpu(), I, J
+
+
 # ------------------------------------------------------------------------------------ file lists
 
 def load_files():
@@ -194,10 +217,13 @@ class SELDDataset(Dataset):
     (dataset.py:243-249) and windows are cut across file boundaries like the reference does.
     """
 
-    def __init__(self, audio_files, metadata_files, num_classes=14, device=None, keep_on_device=True):
+    def __init__(self, audio_files, metadata_files, num_classes=14, device=None, keep_on_device=True,
+                 use_gaussian_augmentation=None):
         assert len(audio_files) == len(metadata_files), \
             "Number of audio files must match number of metadata files"
         self._init_fields(num_classes, device)
+        if use_gaussian_augmentation is not None:          # smrl_seld_gaussian.py:539-560 (train: True, test: False)
+            self.use_gaussian_augmentation = bool(use_gaussian_augmentation)
         self.audio_files = audio_files
         self.metadata_files = metadata_files
         self.keep_on_device = keep_on_device
@@ -228,7 +254,13 @@ class SELDDataset(Dataset):
             raise NotImplementedError(f"sample rate {rate} != {self.sample_rate}: the feature kernel is built for 24 kHz")
         spec = seld_native.logmel(pcm, layout="tcf")                           # [F, C, 64]
         audio_duration = pcm.shape[1] / rate                                   # dataset.py:232 (float64)
-        mask, _, _ = metadata_to_mask(rows, audio_duration, self.I, self.J, device=self.device)
+        if self.use_gaussian_augmentation:                                      # smrl_seld_gaussian.py:608-618
+            mask, _, _ = augment_with_gaussian_mask(rows, audio_duration, self.I, self.J,
+                                                    sigma_azimuth=config.GAUSSIAN_SIGMA_AZIMUTH,
+                                                    sigma_elevation=config.GAUSSIAN_SIGMA_ELEVATION,
+                                                    device=self.device, rng=self._label_rng)
+        else:
+            mask, _, _ = metadata_to_mask(rows, audio_duration, self.I, self.J, device=self.device)
         frames = min(spec.shape[0], mask.shape[0])                             # dataset.py:243-249
         return spec[:frames], mask[:frames]
 
@@ -263,11 +295,14 @@ class SELDDataset(Dataset):
         logger.info(f"Created {len(self.window_starts)} windows")
 
     @classmethod
-    def from_pcm(cls, clips, metadata_rows, sample_rate=24000, num_classes=14, device=None):
+    def from_pcm(cls, clips, metadata_rows, sample_rate=24000, num_classes=14, device=None,
+                 use_gaussian_augmentation=None):
         """Build from in-memory PCM tensors ([C, L] float32 / int16 each) and parsed metadata rows
         (int [R, 5] each) -- used by the benchmark and the tests, same code path as files."""
         self = cls.__new__(cls)
         SELDDataset._init_fields(self, num_classes, device)
+        if use_gaussian_augmentation is not None:
+            self.use_gaussian_augmentation = bool(use_gaussian_augmentation)
         specs, masks = [], []
         for pcm, rows in zip(clips, metadata_rows):
             spec, mask = self._features_from_pcm(pcm.to(self.device), sample_rate, np.asarray(rows))
@@ -290,6 +325,8 @@ class SELDDataset(Dataset):
         self.hop_length_frames = int(self.hop_length_samples / self.spectrogram_hop_length)
         self.device = torch.device(device) if device is not None else _compute_device()
         self.keep_on_device = True
+        self._label_rng = np.random.RandomState(config.SEED) if config.SEED is not None else None
+        self.use_gaussian_augmentation = bool(config.GAUSSIAN_AUGMENT)
 
     # -- reference-shaped views ---------------------------------------------------------------
     @property

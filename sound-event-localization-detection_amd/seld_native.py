@@ -56,6 +56,8 @@ def _declare(lib):
     lib.seld_gcc_phat.argtypes = [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr]
     lib.seld_labels_rasterise.argtypes = [_ptr, _i64, _i64, _int, _int, _ptr, _ptr]
     lib.seld_labels_expand.argtypes = [_ptr, _i64, _int, _ptr, _ptr]
+    lib.seld_labels_rasterise_box.argtypes = [_ptr, _ptr, _i64, _i64, _int, _int, ctypes.c_double, ctypes.c_double, _ptr,
+                                              _ptr]
     lib.seld_window_gather.argtypes = [_ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr]
     lib.seld_softmax_mse_workspace_bytes.restype = _i64
     lib.seld_softmax_mse_workspace_bytes.argtypes = []
@@ -198,6 +200,47 @@ def rasterise_labels(events: torch.Tensor, total_frames: int, I: int = GRID_I, J
     with torch.cuda.device(index):
         check(load_library().seld_labels_rasterise(_p(ev), ev.shape[0], total_frames, I, J, _p(out),
                                                    _stream_ptr(device)), "seld_labels_rasterise")
+    return out
+
+
+def gaussian_source_noise(events, sigma_az: float = 5.0, sigma_el: float = 5.0, rng=None):
+    """One (azimuth, elevation) normal draw per unique (class, source) pair, in the sorted-key order of
+    ``df.groupby([1, 2])`` (smrl_seld_gaussian.py:426-437).  Returns float64 [R, 2]: the box centre of every row.
+    ``rng``: a numpy Generator / RandomState; default ``numpy.random`` (the reference never seeds)."""
+    import numpy as np
+    ev = np.asarray(events)[:, :5].astype(np.int64)
+    rng = np.random if rng is None else rng
+    keys = sorted({(int(c), int(s)) for c, s in ev[:, 1:3]})
+    noise = {k: (rng.normal(0, sigma_az), rng.normal(0, sigma_el)) for k in keys}
+    centres = np.empty((ev.shape[0], 2), dtype=np.float64)
+    for r, row in enumerate(ev):
+        dn = noise[(int(row[1]), int(row[2]))]
+        centres[r] = (row[3] + dn[0], row[4] + dn[1])
+    return centres
+
+
+def rasterise_labels_gaussian(events, centres, total_frames: int, I: int = GRID_I, J: int = GRID_J,
+                              sigma_az: float = 5.0, sigma_el: float = 5.0, device=None) -> torch.Tensor:
+    """smrl_seld_gaussian.py:397-534 on the GPU: uint16 class mask [total_frames, I*J]."""
+    events = torch.as_tensor(events)
+    if events.numel() and not events.is_cuda:
+        cls = events[:, 1]
+        if int(cls.max()) >= NUM_CLASSES or int(cls.min()) < 0:
+            raise IndexError("metadata class index out of range for 14 classes")
+    device = torch.device(device) if device is not None else (events.device if events.is_cuda else None)
+    if device is None:
+        raise SeldNativeError("rasterise_labels_gaussian: pass device= (no CPU fallback)")
+    index = ensure_init(device)
+    ev = events[:, :5].to(device=device, dtype=torch.int32).contiguous() if events.numel() else \
+        torch.zeros((0, 5), dtype=torch.int32, device=device)
+    ctr = torch.as_tensor(centres, dtype=torch.float64).to(device).contiguous().reshape(-1, 2)
+    if ctr.shape[0] != ev.shape[0]:
+        raise ValueError("one box centre per metadata row")
+    out = torch.empty((total_frames, I * J), dtype=torch.uint16, device=device)
+    with torch.cuda.device(index):
+        check(load_library().seld_labels_rasterise_box(_p(ev), _p(ctr), ev.shape[0], total_frames, I, J, float(sigma_az),
+                                                       float(sigma_el), _p(out), _stream_ptr(device)),
+              "seld_labels_rasterise_box")
     return out
 
 

@@ -86,3 +86,47 @@ def test_window_gather_matches_oracle(gpu_device):
 def test_reference_window_counts_on_device(gpu_device):
     for total, expected in [(4470, 90), (3035, 61)]:
         assert len(owin.window_starts(total)) == expected
+
+
+@pytest.mark.parametrize("num_samples,meta_frames,seed", [(24000 * 2 + 100, 20, 1), (240000, 100, 2), (1440000, 600, 3)])
+def test_gaussian_rasteriser_matches_oracle(gpu_device, num_samples, meta_frames, seed):
+    """smrl_seld_gaussian.py:397-534: bit-exact cell sets for the +-2 sigma boxes (float64 comparisons)."""
+    import seld_native
+    rows = olab.synth_metadata(seed, meta_frames=meta_frames)
+    centres = olab.gaussian_source_noise(rows, rng=np.random.RandomState(seed))
+    mine = seld_native.gaussian_source_noise(rows, rng=np.random.RandomState(seed))
+    assert np.array_equal(centres, mine)                    # same draw order as the reference's groupby([1, 2])
+    T = olab.total_label_frames(num_samples)
+    got = seld_native.rasterise_labels_gaussian(torch.from_numpy(rows), centres, T, device=gpu_device)
+    assert got.dtype == torch.uint16 and tuple(got.shape) == (T, 648)
+    assert np.array_equal(got.cpu().numpy(), olab.gaussian_mask(rows, centres, num_samples))
+    if T <= 200:
+        dense = seld_native.expand_labels(got).cpu().numpy()
+        assert np.array_equal(dense, olab.gaussian_labels_loops(rows, centres, num_samples))
+
+
+def test_gaussian_rasteriser_edge_cases(gpu_device):
+    import seld_native
+    empty = seld_native.rasterise_labels_gaussian(torch.zeros((0, 5), dtype=torch.int64), np.zeros((0, 2)), 50,
+                                                  device=gpu_device)
+    assert (empty.cpu().numpy() == 0).all()
+    # seam / pole cases with zero noise, other sigmas, centres exactly on a cell-centre boundary
+    rows = np.array([[0, 3, 0, 175, 0], [1, 4, 0, -178, 85], [2, 5, 1, 10, -88], [3, 6, 2, 5, 5], [40, 1, 0, 0, 0]])
+    centres = rows[:, 3:5].astype(np.float64)
+    for sa, se in [(5.0, 5.0), (2.5, 20.0), (0.0, 0.0), (90.0, 45.0)]:
+        got = seld_native.rasterise_labels_gaussian(torch.from_numpy(rows), centres, 48, sigma_az=sa, sigma_el=se,
+                                                    device=gpu_device).cpu().numpy()
+        assert np.array_equal(got, olab.gaussian_mask(rows, centres, 48 * 480, sigma_azimuth=sa, sigma_elevation=se))
+    with pytest.raises(IndexError):
+        seld_native.rasterise_labels_gaussian(torch.tensor([[0, 14, 0, 0, 0]]), np.zeros((1, 2)), 10, device=gpu_device)
+
+
+def test_dataset_gaussian_augmentation_flag(gpu_device):
+    """SELDDataset(use_gaussian_augmentation=True) (smrl_seld_gaussian.py:539-618) paints boxes, the default does not."""
+    from dataset import SELDDataset
+    rows = olab.synth_metadata(9, meta_frames=100)
+    pcm = torch.zeros((4, 240000), dtype=torch.int16)
+    plain = SELDDataset.from_pcm([pcm], [rows], device=gpu_device)
+    aug = SELDDataset.from_pcm([pcm], [rows], device=gpu_device, use_gaussian_augmentation=True)
+    a, b = (plain.mask_tm != 0).sum().item(), (aug.mask_tm != 0).sum().item()
+    assert b > 2 * a > 0
