@@ -125,29 +125,54 @@ int seld_softmax_mse(const void* logits, int logits_is_bf16, const uint16_t* mas
                      int64_t n_cells, int num_classes, float grad_scale, float* loss_out, void* grad,
                      void* workspace, void* stream);
 
+/* ---- CNN block tail: BatchNorm2d -> ReLU -> MaxPool2d((1,2)) at model_crnn.py:5-17 (ConvBlock.forward) ---- */
+/* x: the convolution output in channels-last memory order = row-major [rows = B*T*F][C] (bf16 when is_bf16, else
+ * fp32); the two frequency bins of a pooling pair are adjacent rows.  pool = 2: MaxPool2d((1,2)); pool = 1: no
+ * pooling.  C must be 8 * (a divisor of 256); rows a multiple of pool.
+ * forward, training != 0: batch statistics (biased variance), running_mean / running_var updated with `momentum`
+ *   (unbiased variance) exactly like nn.BatchNorm2d; training == 0: the running statistics are used.
+ *   y [rows/pool][C] (dtype of x) = max over the pair of relu(weight * (x - mean) * invstd + bias), with the
+ *   BatchNorm output rounded to the activation dtype before the comparisons like the unfused modules.
+ *   mean_invstd [2][C], scale_shift [2][C] (a = weight*invstd, b = bias - mean*a): outputs, kept for backward.
+ * backward: dx [rows][C] (dtype of x), dweight [C], dbias [C] from dy [rows/pool][C]; the ReLU mask and pooling
+ *   argmax are recomputed from x (first element wins ties, as max_pool2d).
+ * workspace: seld_conv_tail_workspace_floats(C) floats of device scratch.  Deterministic (no float atomics). */
+int64_t seld_conv_tail_workspace_floats(int C);
+int seld_conv_tail_forward(const void* x, int is_bf16, int64_t rows, int C, int pool, const float* weight,
+                           const float* bias, float* running_mean, float* running_var, float momentum, float eps,
+                           int training, void* y, float* mean_invstd, float* scale_shift, float* workspace,
+                           void* stream);
+int seld_conv_tail_backward(const void* x, const void* dy, int is_bf16, int64_t rows, int C, int pool,
+                            const float* mean_invstd, const float* scale_shift, void* dx, float* dweight,
+                            float* dbias, float* workspace, void* stream);
+
 /* ---- recurrence: nn.GRU(2048, 256, num_layers=2, bidirectional) at model_crnn.py:65-72 ------- */
 /* One bidirectional GRU layer's recurrence, all T steps in one launch (both directions), H = 256.
- * The batch is processed in tiles of seld_gru_tile_rows() = 16 sequences (pad B up to a whole tile).
+ * The batch is processed in tiles of seld_gru_tile_rows() = 8 sequences (pad B up to a whole tile): one
+ * workgroup per (tile, direction); half of each 16-column MFMA is padding so that the per-CU vector-memory
+ * and gate-math work of a step -- what bounds it once the weights are resident -- is spread over more CUs.
  *
  * Streamed per-step tensors use the kernels' private TILE LAYOUT so that every wavefront load / store
- * is one contiguous 512 B / 1 KB run: a tensor X[b][t][dir][slot][u] (b = 16*tile + c, u = 32*w + 16*s +
- * 4*q + i) is stored as  [tile][t][dir][w(8)][s(2)][slot(NS)][q(4)][c(16)][i(4)]  (seld_native.to_tile /
+ * is one contiguous 512 B / 1 KB run: a tensor X[b][t][dir][slot][u] (b = 8*tile + seq, u = 32*w + 16*s +
+ * 4*q + i) is stored as  [tile][t][dir][w(8)][slot(NS)][q(4)][s(2)][seq(8)][i(4)]  (seld_native.to_tile /
  * from_tile do the permutes).
  *   gi_tile    NS=3  input projections x W_ih^T + b_ih, gates r|z|n, direction 0 = forward in time,
  *                    1 = reverse (fp32, or bf16 when is_bf16).  The recurrent biases of the r and z gates
  *                    (b_hh[0:2H]) must ALREADY be added in (they commute with the sigmoid argument).
  *   w_hh       [2][3H][H] bf16;   b_hn [2][H] fp32 (= b_hh[2H:3H] per direction);   h0 = 0
- *   y          [tiles*16][T][2H] natural layout (h_t; forward direction in [..., :H]), dtype of gi
- *   saved_tile NS=5  fp32: r, z, n, (W_hn h + b_hn), h per step for the backward pass, or NULL
+ *   y          [tiles*8][T][2H] natural layout (h_t; forward direction in [..., :H]), dtype of gi
+ *   saved_tile NS=5  r, z, n, (W_hn h + b_hn), h per step for the backward pass, or NULL; fp32 when gi is
+ *                    fp32, IEEE fp16 when is_bf16 (O(1) values: 8x finer than bf16 at half of fp32's bytes --
+ *                    the recurrence is bound by one CU's load/store path)
  * MFMA bf16 operands, fp32 accumulation, fp32 gates and state. */
 int64_t seld_gru_tile_rows(void);
 int seld_gru_forward(const void* gi_tile, int is_bf16, const void* w_hh_bf16, const float* b_hn, int64_t tiles,
-                     int64_t T, int64_t H, void* y, float* saved_tile, void* stream);
+                     int64_t T, int64_t H, void* y, void* saved_tile, void* stream);
 
 /* Backward of the recurrence.  dy_tile NS=1 (dtype of y), w_hh_t [2][H][3H] bf16 (W_hh transposed).
  * dg_tile NS=4 (dtype of y): da_r, da_z, da_n, da_n*r -- the first three are d/d(gi); slots (0, 1, 3) are
  * d/d(gh), from which the caller forms dW_hh = dgh^T h_prev, db_hh, and with gi's GEMM dW_ih, db_ih, dx. */
-int seld_gru_backward(const void* dy_tile, const float* saved_tile, int is_bf16, const void* w_hh_t_bf16,
+int seld_gru_backward(const void* dy_tile, const void* saved_tile, int is_bf16, const void* w_hh_t_bf16,
                       int64_t tiles, int64_t T, int64_t H, void* dg_tile, void* stream);
 
 #ifdef __cplusplus

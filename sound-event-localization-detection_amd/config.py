@@ -90,6 +90,7 @@ class Config:
     AMP_DTYPE = "bf16"          # autocast dtype on ROCm devices: 'bf16' or 'fp32'
     CHANNELS_LAST = True        # NHWC conv blocks (MIOpen/hipBLASLt MFMA path)
     FUSED_LOSS = True           # seld_softmax_mse instead of softmax + mse_loss + autograd
+    FUSED_CONV_TAIL = True      # BatchNorm -> ReLU -> MaxPool of the CNN blocks in two HBM passes (csrc/convtail.hip)
     FUSED_GRU = True            # persistent BiGRU kernel instead of MIOpen's per-step GEMMs
     DEVICE_FEED = True          # train from device-resident features / compact labels (no 290 MB/step H2D)
     DDP_BUCKET_MB = 25          # RCCL all-reduce bucket size

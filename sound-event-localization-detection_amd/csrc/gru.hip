@@ -7,19 +7,25 @@
 //     gh = h W_hh^T + b_hh ;  r = s(gi_r + gh_r) ; z = s(gi_z + gh_z) ; n = tanh(gi_n + r*gh_n)
 //     h' = (1 - z) n + z h
 // which a library executes as ~2 tiny kernels per step.  Here ONE workgroup per (direction,
-// 16-sequence batch tile) runs all T steps with W_hh resident on the CU:
-//   * 8 wavefronts; wavefront w owns hidden units [32w, 32w+32) for all three gates, so the gate
-//     math of a (sequence, unit) pair is lane-local and h stays in fp32 registers;
+// 8-sequence batch tile) runs all T steps with W_hh resident on the CU:
+//   * 8 wavefronts; wavefront w owns hidden units [32w, 32w+32) for all three gates;
 //   * W_hh (bf16, 393 KB per direction) does not fit one place: the r and z gate rows live in
-//     VGPRs as MFMA B-fragments (128 registers per lane), the n gate rows in LDS (128 KB) laid
+//     VGPRs as MFMA A-fragments (128 registers per lane), the n gate rows in LDS (128 KB) laid
 //     out fragment-major so every ds_read_b128 is a linear conflict-free 1 KB read;
 //   * h_{t-1} (bf16) is exchanged through a double-buffered 16 x 256 LDS tile (row pitch 528 B:
-//     conflict-free A-fragment reads), one barrier per step;
+//     conflict-free B-fragment reads), one barrier per step;
 //   * v_mfma_f32_16x16x32_bf16: per step 48 MFMAs per wavefront, fp32 accumulate, fp32 gates.
-// At M = 16 rows the step is MFMA-issue bound on its CU (~0.65 us); the 250-step recurrence of one
-// layer costs about a quarter of a millisecond instead of hundreds of launches.
 //
-// The backward kernel mirrors it: dgh (bf16) goes through LDS as the A operand, W_hh^T fragments
+// WHY ONLY 8 SEQUENCES PER 16-COLUMN MFMA TILE.  With the weights resident, a step is bound by what ONE CU
+// can do besides the MFMAs: its vector-memory path sustains only ~10-15 B/clk (MI355X_MICROARCH.md: "~10
+// B/cyc/CU"), and the gate math (6 transcendentals per element) issues on the same 4 SIMDs.  Both scale
+// with sequences per CU while the MFMA time (96 per SIMD, ~1.5k cycles) does not -- so the batch is spread over
+// TWICE the CUs: columns 8..15 of every MFMA are padding (zero h rows), and after the MFMAs lane (q, c >= 8)
+// takes over the second 16-unit tile of lane (q, c - 8) with one DPP row-shift per value.  Every lane then
+// owns ONE (sequence, 4 units) group: half the gate instructions and half the bytes per CU per step, all 64
+// lanes active in every load and store.  Measured (B = 32, T = 250): see DESIGN.md section 5.4.
+//
+// The backward kernel mirrors it: dgh (bf16) goes through LDS as the B operand, W_hh^T fragments
 // are register / LDS resident, dh is carried in registers; it emits the per-step gate gradients
 // from which the host forms dW_ih, dW_hh, dx with three large GEMMs.
 #include <hip/hip_bf16.h>
@@ -30,7 +36,8 @@ namespace seld {
 
 constexpr int kH = 256;            // hidden size (config.py:45 CRNN_RNN_HIDDEN)
 constexpr int kG = 3 * kH;         // gate rows r | z | n
-constexpr int kRows = 16;          // sequences per workgroup (MFMA M)
+constexpr int kRows = 16;          // MFMA N (columns); rows of the LDS exchange tiles
+constexpr int kSeqs = 8;           // sequences per workgroup (columns 0..7; 8..15 are padding)
 constexpr int kGruThreads = 512;   // 8 wavefronts
 constexpr int kHPitch = kH + 8;    // bf16 elements per h row in LDS (528 B)
 constexpr int kDghPitch = kG + 8;  // bf16 elements per dgh row in LDS (1552 B)
@@ -49,6 +56,12 @@ template <> __device__ __forceinline__ __hip_bfloat16 from_float<__hip_bfloat16>
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // tanh(x) = 1 - 2 / (1 + e^{2x}): saturates correctly (e = inf -> 1, e = 0 -> -1) without a clamp
 __device__ __forceinline__ float tanh_f(float x) { return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)), 1.0f); }
+
+// Lanes 8..15 of every 16-lane row take `hi` from the lane 8 to their left (row_shr:8), lanes 0..7 keep `lo`.
+// bank_mask 0b1100 enables the write for banks 2, 3 (lanes 8..15 of the row) only.
+__device__ __forceinline__ float take_second_tile(float lo, float hi) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lo), __float_as_int(hi), 0x118, 0xf, 0xc, false));
+}
 
 // 4 consecutive hidden units of one sequence, as stored in global memory
 template <typename T> struct Vec4;
@@ -69,96 +82,114 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ void pack4(const float (&f)[4], float4& v) { v = make_float4(f[0], f[1], f[2], f[3]); }
 __device__ __forceinline__ void pack4(const float (&f)[4], uint2& v) { v = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3])); }
 
+// Saved activations (r, z, n, gh_n, h) for the backward pass: fp32 in the fp32 build; fp16 in the bf16 build
+// (all five are O(1) values -- r, z in (0,1), n, h in (-1,1) -- so fp16's 11-bit significand keeps them 8x
+// finer than bf16 would, at half of fp32's bytes).
+template <typename T> struct SavedVec;
+template <> struct SavedVec<float> { typedef float4 type; };
+template <> struct SavedVec<__hip_bfloat16> { typedef uint2 type; };
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  const f16x2 hv = __builtin_convertvector(v, f16x2);       // round to nearest even
+  return __builtin_bit_cast(unsigned, hv);
+}
+__device__ __forceinline__ void pack_saved(const float (&f)[4], float4& v) { v = make_float4(f[0], f[1], f[2], f[3]); }
+__device__ __forceinline__ void pack_saved(const float (&f)[4], uint2& v) {
+  v = make_uint2(pack_f16x2(f[0], f[1]), pack_f16x2(f[2], f[3]));
+}
+__device__ __forceinline__ void unpack_saved(const float4& v, float (&f)[4]) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
+__device__ __forceinline__ void unpack_saved(const uint2& v, float (&f)[4]) {
+  const f16x2 a = __builtin_bit_cast(f16x2, v.x), b = __builtin_bit_cast(f16x2, v.y);
+  f[0] = static_cast<float>(a[0]);
+  f[1] = static_cast<float>(a[1]);
+  f[2] = static_cast<float>(b[0]);
+  f[3] = static_cast<float>(b[1]);
+}
+
 // ---- private "tile" layout of every per-step tensor the kernels stream (gi, saved gates, dy, dg) --------
-// A lane (q = lane>>4, c = lane&15) of wavefront w owns sequence c of its 16-sequence tile and units
-// 32w + 16s + 4q .. +3.  Storing the 4-unit group of lane `lane` at
-//     group(tile, t, dir, w, s, slot, lane) = ((((((tile*T + t)*2 + dir)*8 + w)*2 + s)*NS + slot)*64 + lane)
+// Lane (q = lane>>4, c = lane&15) of wavefront w owns sequence (c & 7) of its 8-sequence tile and the 4 units
+// 32w + 16(c>>3) + 4q .. +3.  Storing the 4-unit group of lane `lane` at
+//     group(tile, t, dir, w, slot, lane) = (((((tile*T + t)*2 + dir)*8 + w)*NS + slot)*64 + lane)
 // (x4 elements) makes every load / store instruction of a wavefront ONE contiguous 512 B / 1 KB run.
-// In the natural [B][T][...][H] layout the same instruction touches 16 rows x 32..64 B: measured, the
-// CU's store path then takes ~1.6 us per step for the 10 stores of a step -- more than all the arithmetic.
+// In the natural [B][T][...][H] layout the same instruction touches 8 rows x 32..64 B: measured, the
+// CU's store path then takes ~1.6 us per step for the stores of a step -- more than all the arithmetic.
 // The host converts gi / dy into this layout and dg back with one permute each (tens of MB, microseconds).
-__device__ __forceinline__ long tile_group(long tile, long T, long t, int dir, int w, int s, int ns, int slot, int lane) {
-  return ((((((tile * T + t) * 2 + dir) * 8 + w) * 2 + s) * ns + slot) * 64 + lane);
+__device__ __forceinline__ long tile_group(long tile, long T, long t, int dir, int w, int ns, int slot, int lane) {
+  return (((((tile * T + t) * 2 + dir) * 8 + w) * ns + slot) * 64 + lane);
 }
 
 struct GruFwdArgs {
   const void* gi;        // tile layout, NS = 3 (r | z | n), dtype T; r/z already include b_hh
   const __hip_bfloat16* w_hh;   // [2][3H][H]
   const float* b_hn;     // [2][H]    recurrent bias of the n gate
-  void* y;               // [tiles*16][T][2H]  natural layout (what the next layer's GEMM reads), dtype T
-  float* saved;          // tile layout, NS = 5 (r, z, n, gh_n, h), always fp32 (nullptr: inference)
+  void* y;               // [tiles*8][T][2H]  natural layout (what the next layer's GEMM reads), dtype T
+  void* saved;           // tile layout, NS = 5 (r, z, n, gh_n, h), SavedVec<T> groups (nullptr: inference)
   long tiles, T;
 };
 
-// The MFMA computes gh^T = W_hh h^T: M = gate rows (units), N = the 16 sequences of the tile; with
-// D[m = 4q+i][n = c] the gate math of a lane is local and every access is an 8- or 16-byte vector.
-// The step body has NO divergent control flow (batch padded to whole tiles by the host; kSave compile
-// time): the compiler counts outstanding loads / stores exactly and never drains the queue.
+// The MFMA computes gh^T = W_hh h^T: M = gate rows (units), N = sequence columns; with D[m = 4q+i][n = c] a lane
+// holds 4 consecutive units of one column.  The step body has NO divergent control flow (batch padded to whole
+// tiles by the host; kSave compile time): the compiler counts outstanding loads / stores exactly and never
+// drains the queue.
 template <typename T, bool kSave>
 __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* wn_lds, __hip_bfloat16* hbuf,
                                                   const bf16x8 (&wr)[2][8], const bf16x8 (&wz)[2][8]) {
   typedef typename Vec4<T>::type V4;
+  typedef typename SavedVec<T>::type SV;
   constexpr bool kLdsY = sizeof(T) == 2;   // bf16: y rows are written from the LDS h tile (512-B runs)
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int q = lane >> 4, c = lane & 15;
+  const int seq = c & 7, s_own = c >> 3;
+  const int unit0 = 32 * wave + 16 * s_own + 4 * q;       // the 4 units this lane post-processes
   const int dir = blockIdx.y;
   const long tile = blockIdx.x;
   const float* bh = a.b_hn + dir * kH;
   const V4* gi = static_cast<const V4*>(a.gi);
   T* y = static_cast<T*>(a.y);
-  float4* saved = reinterpret_cast<float4*>(a.saved);
-  const long b = tile * kRows + c;         // this lane's sequence (natural-layout row)
+  SV* saved = static_cast<SV*>(a.saved);
+  const long b = tile * kSeqs + seq;       // this lane's sequence (natural-layout row)
 
-  float bias_n[2][4];
-  float h_prev[2][4];
+  float bias_n[4], h_prev[4];
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      bias_n[s][i] = bh[32 * wave + 16 * s + 4 * q + i];
-      h_prev[s][i] = 0.0f;
-    }
+  for (int i = 0; i < 4; ++i) {
+    bias_n[i] = bh[unit0 + i];
+    h_prev[i] = 0.0f;
+  }
 
   auto time_of = [&](long step) { return dir == 0 ? step : a.T - 1 - step; };
-  auto load_gi = [&](long step, V4 (&g)[2][3]) {
-    // one base pointer per step + compile-time offsets (s*3*64 + gate*64 groups): a single address register
-    const V4* p = gi + tile_group(tile, a.T, time_of(step), dir, wave, 0, 3, 0, lane);
+  auto load_gi = [&](long step, V4 (&g)[3]) {
+    // one base pointer per step + compile-time offsets (gate*64 groups): a single address register
+    const V4* p = gi + tile_group(tile, a.T, time_of(step), dir, wave, 3, 0, lane);
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int gate = 0; gate < 3; ++gate) g[s][gate] = p[(s * 3 + gate) * 64];
+    for (int gate = 0; gate < 3; ++gate) g[gate] = p[gate * 64];
   };
 
   // `g` holds this step's operands on entry; they are unpacked at once and the SAME registers then receive
   // the next step's operands (a whole step of cover), so no second operand set is needed.
-  auto step = [&](long t, V4 (&g)[2][3]) {
+  auto step = [&](long t, V4 (&g)[3]) {
     const long tt = time_of(t);
     const int cur = static_cast<int>(t & 1), nxt = cur ^ 1;
-    float4* const save_base = kSave ? saved + tile_group(tile, a.T, tt, dir, wave, 0, 5, 0, lane) : nullptr;
-    f32x4 acc_r[2], acc_z[2], acc_n[2];
-    float gin[2][4];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      float gr[4], gz[4];
-      unpack4(g[s][0], gr);
-      unpack4(g[s][1], gz);
-      unpack4(g[s][2], gin[s]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        acc_r[s][i] = gr[i];               // gi already holds b_ih + b_hh for the r and z gates
-        acc_z[s][i] = gz[i];
-        acc_n[s][i] = bias_n[s][i];
-      }
-    }
+    SV* const save_base = kSave ? saved + tile_group(tile, a.T, tt, dir, wave, 5, 0, lane) : nullptr;
+    float gir[4], giz[4], gin[4];
+    unpack4(g[0], gir);                    // gi already holds b_ih + b_hh for the r and z gates
+    unpack4(g[1], giz);
+    unpack4(g[2], gin);
     // operands of the next step: unconditional (clamped at the last step) and pinned here -- the scheduler
     // otherwise sinks the loads below this step's stores, and the in-order vmcnt then makes the next step
     // wait for those stores' round trip.
     __builtin_amdgcn_sched_barrier(0);
     load_gi(t + 1 < a.T ? t + 1 : a.T - 1, g);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- gh^T = W_hh h^T : B fragments (k, n = sequence c) of h_{t-1} and the n-gate A fragments from LDS,
+    // ---- gh^T = W_hh h^T : B fragments (k, n = column c) of h_{t-1} and the n-gate A fragments from LDS,
     // read one k-step ahead of the MFMAs that consume them (the LDS latency hides under 6 MFMAs)
+    f32x4 acc_r[2], acc_z[2], acc_n[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc_r[s][i] = acc_z[s][i] = acc_n[s][i] = 0.0f;
     const __hip_bfloat16* hrow = hbuf + (cur * kRows + c) * kHPitch + 8 * q;
     const bf16x8* wnp = wn_lds + wave * 2 * 8 * 64 + lane;
     bf16x8 hfrag = *reinterpret_cast<const bf16x8*>(hrow);
@@ -181,47 +212,50 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
       wn0 = wn0_n;
       wn1 = wn1_n;
     }
-    // ---- gates (lane-local: sequence c, units 4q..4q+3 of each tile) and state update
+    // ---- gates for this lane's (sequence, 4 units): columns 0..7 keep unit tile 0, columns 8..15 take unit
+    // tile 1 of the column 8 to their left
+    float rr[4], zz[4], nn[4], gg[4], hh[4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int unit0 = 32 * wave + 16 * s + 4 * q;
-      float rr[4], zz[4], nn[4], gg[4], hh[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        rr[i] = sigmoid_f(acc_r[s][i]);
-        zz[i] = sigmoid_f(acc_z[s][i]);
-        gg[i] = acc_n[s][i];
-        nn[i] = tanh_f(fmaf(rr[i], gg[i], gin[s][i]));
-        hh[i] = fmaf(zz[i], h_prev[s][i] - nn[i], nn[i]);
-        h_prev[s][i] = hh[i];
-      }
-      uint2 hb;
-      pack4(hh, hb);
-      *reinterpret_cast<uint2*>(hbuf + (nxt * kRows + c) * kHPitch + unit0) = hb;
-      if (!kLdsY) {
-        V4 yv;
-        pack4(hh, yv);
-        *reinterpret_cast<V4*>(y + (b * a.T + tt) * (2 * kH) + dir * kH + unit0) = yv;
-      }
-      if (kSave) {
-        float4* sp = save_base + s * 5 * 64;
-        sp[0] = make_float4(rr[0], rr[1], rr[2], rr[3]);
-        sp[64] = make_float4(zz[0], zz[1], zz[2], zz[3]);
-        sp[128] = make_float4(nn[0], nn[1], nn[2], nn[3]);
-        sp[192] = make_float4(gg[0], gg[1], gg[2], gg[3]);
-        sp[256] = make_float4(hh[0], hh[1], hh[2], hh[3]);
-      }
+    for (int i = 0; i < 4; ++i) {
+      const float ghr = take_second_tile(acc_r[0][i], acc_r[1][i]);
+      const float ghz = take_second_tile(acc_z[0][i], acc_z[1][i]);
+      gg[i] = take_second_tile(acc_n[0][i], acc_n[1][i]) + bias_n[i];
+      rr[i] = sigmoid_f(gir[i] + ghr);
+      zz[i] = sigmoid_f(giz[i] + ghz);
+      nn[i] = tanh_f(fmaf(rr[i], gg[i], gin[i]));
+      hh[i] = fmaf(zz[i], h_prev[i] - nn[i], nn[i]);
+      h_prev[i] = hh[i];
+    }
+    uint2 hb;
+    pack4(hh, hb);
+    *reinterpret_cast<uint2*>(hbuf + (nxt * kRows + seq) * kHPitch + unit0) = hb;
+    if (!kLdsY) {
+      V4 yv;
+      pack4(hh, yv);
+      *reinterpret_cast<V4*>(y + (b * a.T + tt) * (2 * kH) + dir * kH + unit0) = yv;
+    }
+    if (kSave) {
+      SV v;
+      pack_saved(rr, v);
+      save_base[0] = v;
+      pack_saved(zz, v);
+      save_base[64] = v;
+      pack_saved(nn, v);
+      save_base[128] = v;
+      pack_saved(gg, v);
+      save_base[192] = v;
+      pack_saved(hh, v);
+      save_base[256] = v;
     }
     __syncthreads();
     if (kLdsY) {
-      // y[b][tt][dir*H .. +H) is a 512-B run: wavefront w writes rows 2w and 2w+1 of the fresh h tile
-      const int row = 2 * wave + (lane >> 5), col = (lane & 31) * 8;
-      const uint4 v = *reinterpret_cast<const uint4*>(hbuf + (nxt * kRows + row) * kHPitch + col);
-      *reinterpret_cast<uint4*>(y + ((tile * kRows + row) * a.T + tt) * (2 * kH) + dir * kH + col) = v;
+      // y[b][tt][dir*H .. +H) is a 512-B run: wavefront w writes row w of the fresh h tile
+      const uint2 v = *reinterpret_cast<const uint2*>(hbuf + (nxt * kRows + wave) * kHPitch + lane * 4);
+      *reinterpret_cast<uint2*>(y + ((tile * kSeqs + wave) * a.T + tt) * (2 * kH) + dir * kH + lane * 4) = v;
     }
   };
 
-  V4 g[2][3];
+  V4 g[3];
   load_gi(0, g);
   // The first step is peeled so that the loop is ENTERED in the same memory-queue state as the back edge
   // leaves it; otherwise the compiler merges the two states conservatively and every step waits for the
@@ -255,6 +289,7 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs 
           *reinterpret_cast<const bf16x8*>(w + static_cast<long>(2 * kH + unit) * kH + k0);
     }
   }
+  // rows 8..15 of both h tiles are never written again: the padding columns of every MFMA stay zero
   for (int i = tid; i < 2 * kRows * kHPitch; i += kGruThreads) hbuf[i] = __float2bfloat16(0.0f);
   __syncthreads();
   if (a.saved) gru_forward_steps<T, true>(a, wn_lds, hbuf, wr, wz);
@@ -263,109 +298,96 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs 
 
 struct GruBwdArgs {
   const void* dy;        // tile layout, NS = 1, dtype T
-  const float* saved;    // tile layout, NS = 5 (r, z, n, gh_n, h), fp32
+  const void* saved;     // tile layout, NS = 5 (r, z, n, gh_n, h), SavedVec<T> groups
   const __hip_bfloat16* w_hh_t;   // [2][H][3H]   W_hh transposed per direction
   void* dg;              // tile layout, NS = 4 (da_r, da_z, da_n, da_n * r), dtype T
   long tiles, T;
 };
 
 template <typename T> struct GruStepIn {
-  float4 r[2], z[2], n[2], g[2], hp[2];
-  typename Vec4<T>::type d[2];
+  typename SavedVec<T>::type r, z, n, g, hp;
+  typename Vec4<T>::type d;
 };
 
-// dh_prev^T = W_hh^T dgh^T : M = hidden units, N = sequences; same lane ownership as the forward kernel.
+// dh_prev^T = W_hh^T dgh^T : M = hidden units, N = sequence columns; same lane ownership as the forward kernel.
 template <typename T>
 __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* wn_lds, __hip_bfloat16* dgh,
                                                    const bf16x8 (&wrz)[2][16]) {
   typedef typename Vec4<T>::type V4;
+  typedef typename SavedVec<T>::type SV;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int q = lane >> 4, c = lane & 15;
+  const int seq = c & 7, s_own = c >> 3;
+  const int unit0 = 32 * wave + 16 * s_own + 4 * q;
   const int dir = blockIdx.y;
   const long tile = blockIdx.x;
   const V4* dy = static_cast<const V4*>(a.dy);
-  const float4* saved = reinterpret_cast<const float4*>(a.saved);
+  const SV* saved = static_cast<const SV*>(a.saved);
   V4* dg = static_cast<V4*>(a.dg);
 
-  float dh[2][4];
+  float dh[4];
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dh[s][i] = 0.0f;
+  for (int i = 0; i < 4; ++i) dh[i] = 0.0f;
 
   auto time_of = [&](long step) { return dir == 0 ? step : a.T - 1 - step; };
   auto load_step = [&](long step, GruStepIn<T>& in) {
     const long tt = time_of(step);
     const long tprev = time_of(step > 0 ? step - 1 : 0);      // h_{t-1} of the forward recurrence (unused at step 0)
-    const float4* sp0 = saved + tile_group(tile, a.T, tt, dir, wave, 0, 5, 0, lane);
-    const float4* hp0 = saved + tile_group(tile, a.T, tprev, dir, wave, 0, 5, 4, lane);
-    const V4* dp0 = dy + tile_group(tile, a.T, tt, dir, wave, 0, 1, 0, lane);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      in.r[s] = sp0[s * 5 * 64];
-      in.z[s] = sp0[s * 5 * 64 + 64];
-      in.n[s] = sp0[s * 5 * 64 + 128];
-      in.g[s] = sp0[s * 5 * 64 + 192];
-      in.hp[s] = hp0[s * 5 * 64];
-      in.d[s] = dp0[s * 64];
-    }
+    const SV* sp = saved + tile_group(tile, a.T, tt, dir, wave, 5, 0, lane);
+    in.r = sp[0];
+    in.z = sp[64];
+    in.n = sp[128];
+    in.g = sp[192];
+    in.hp = saved[tile_group(tile, a.T, tprev, dir, wave, 5, 4, lane)];
+    in.d = dy[tile_group(tile, a.T, tt, dir, wave, 1, 0, lane)];
   };
 
   // `in` holds this step's operands on entry; they are unpacked at once and the same registers then receive
   // the operands of the next (earlier-in-time) step.
   auto step = [&](long t, GruStepIn<T>& in) {
     const long tt = time_of(t);
-    float r[2][4], z[2][4], n[2][4], g[2][4], hp[2][4], d[2][4];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      unpack4(in.r[s], r[s]);
-      unpack4(in.z[s], z[s]);
-      unpack4(in.n[s], n[s]);
-      unpack4(in.g[s], g[s]);
-      unpack4(in.hp[s], hp[s]);
-      unpack4(in.d[s], d[s]);
-    }
+    float r[4], z[4], n[4], g[4], hp[4], d[4];
+    unpack_saved(in.r, r);
+    unpack_saved(in.z, z);
+    unpack_saved(in.n, n);
+    unpack_saved(in.g, g);
+    unpack_saved(in.hp, hp);
+    unpack4(in.d, d);
     __builtin_amdgcn_sched_barrier(0);
     load_step(t > 0 ? t - 1 : 0, in);              // unconditional, clamped; pinned ahead of this step's stores
     __builtin_amdgcn_sched_barrier(0);
-    float keep[2][4];
-    V4* const dg_base = dg + tile_group(tile, a.T, tt, dir, wave, 0, 4, 0, lane);
+    float keep[4], da_r[4], da_z[4], da_n[4], dghn[4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int unit0 = 32 * wave + 16 * s + 4 * q;
-      float da_r[4], da_z[4], da_n[4], dghn[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float hprev = t > 0 ? hp[s][i] : 0.0f;
-        const float dtot = d[s][i] + dh[s][i];
-        const float dn = dtot * (1.0f - z[s][i]);
-        const float dz = dtot * (hprev - n[s][i]);
-        da_n[i] = dn * (1.0f - n[s][i] * n[s][i]);
-        da_z[i] = dz * z[s][i] * (1.0f - z[s][i]);
-        da_r[i] = da_n[i] * g[s][i] * r[s][i] * (1.0f - r[s][i]);
-        dghn[i] = da_n[i] * r[s][i];
-        keep[s][i] = dtot * z[s][i];
-      }
-      V4* gp = dg_base + s * 4 * 64;
-      V4 v;
-      pack4(da_r, v);
-      gp[0] = v;
-      pack4(da_z, v);
-      gp[64] = v;
-      pack4(da_n, v);
-      gp[128] = v;
-      pack4(dghn, v);
-      gp[192] = v;
-      __hip_bfloat16* drow = dgh + c * kDghPitch + unit0;
-      uint2 pk;
-      pack4(da_r, pk);
-      *reinterpret_cast<uint2*>(drow) = pk;
-      pack4(da_z, pk);
-      *reinterpret_cast<uint2*>(drow + kH) = pk;
-      pack4(dghn, pk);
-      *reinterpret_cast<uint2*>(drow + 2 * kH) = pk;
+    for (int i = 0; i < 4; ++i) {
+      const float hprev = t > 0 ? hp[i] : 0.0f;
+      const float dtot = d[i] + dh[i];
+      const float dn = dtot * (1.0f - z[i]);
+      const float dz = dtot * (hprev - n[i]);
+      da_n[i] = dn * (1.0f - n[i] * n[i]);
+      da_z[i] = dz * z[i] * (1.0f - z[i]);
+      da_r[i] = da_n[i] * g[i] * r[i] * (1.0f - r[i]);
+      dghn[i] = da_n[i] * r[i];
+      keep[i] = dtot * z[i];
     }
+    V4* const gp = dg + tile_group(tile, a.T, tt, dir, wave, 4, 0, lane);
+    V4 v;
+    pack4(da_r, v);
+    gp[0] = v;
+    pack4(da_z, v);
+    gp[64] = v;
+    pack4(da_n, v);
+    gp[128] = v;
+    pack4(dghn, v);
+    gp[192] = v;
+    __hip_bfloat16* drow = dgh + seq * kDghPitch + unit0;
+    uint2 pk;
+    pack4(da_r, pk);
+    *reinterpret_cast<uint2*>(drow) = pk;
+    pack4(da_z, pk);
+    *reinterpret_cast<uint2*>(drow + kH) = pk;
+    pack4(dghn, pk);
+    *reinterpret_cast<uint2*>(drow + 2 * kH) = pk;
     __syncthreads();
 
     // two independent accumulator chains per unit tile (even / odd k-steps): with a single chain per tile the
@@ -374,10 +396,7 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        acc[s][0][i] = keep[s][i];
-        acc[s][1][i] = 0.0f;
-      }
+      for (int i = 0; i < 4; ++i) acc[s][0][i] = acc[s][1][i] = 0.0f;
     const __hip_bfloat16* brow = dgh + c * kDghPitch + 8 * q;
     const bf16x8* wnp = wn_lds + wave * 2 * 8 * 64 + lane;
     // LDS fragments are read two k-steps ahead of the MFMAs that consume them
@@ -398,9 +417,8 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
       d1 = d2;
     }
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dh[s][i] = acc[s][0][i] + acc[s][1][i];
+    for (int i = 0; i < 4; ++i)
+      dh[i] = keep[i] + take_second_tile(acc[0][0][i] + acc[0][1][i], acc[1][0][i] + acc[1][1][i]);
     __syncthreads();
   };
 
@@ -434,6 +452,8 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_backward_kernel(GruBwdArgs
       wn_lds[((wave * 2 + s) * 8 + kk) * 64 + lane] =
           *reinterpret_cast<const bf16x8*>(wt + static_cast<long>(unit) * kG + 2 * kH + 32 * kk + 8 * q);
   }
+  // rows 8..15 (padding columns of the MFMA) stay zero for the whole kernel
+  for (int i = tid; i < kRows * kDghPitch; i += kGruThreads) dgh[i] = __float2bfloat16(0.0f);
   __syncthreads();
   gru_backward_steps<T>(a, wn_lds, dgh, wrz);
 }
@@ -442,10 +462,10 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_backward_kernel(GruBwdArgs
 
 extern "C" {
 
-int64_t seld_gru_tile_rows(void) { return seld::kRows; }
+int64_t seld_gru_tile_rows(void) { return seld::kSeqs; }
 
 int seld_gru_forward(const void* gi_tile, int is_bf16, const void* w_hh_bf16, const float* b_hn, int64_t tiles,
-                     int64_t T, int64_t H, void* y, float* saved_tile, void* stream_) {
+                     int64_t T, int64_t H, void* y, void* saved_tile, void* stream_) {
   using namespace seld;
   DeviceState* st = current_state();
   if (!st) return kErrNotInitialised;
@@ -470,7 +490,7 @@ int seld_gru_forward(const void* gi_tile, int is_bf16, const void* w_hh_bf16, co
   return kOk;
 }
 
-int seld_gru_backward(const void* dy_tile, const float* saved_tile, int is_bf16, const void* w_hh_t_bf16,
+int seld_gru_backward(const void* dy_tile, const void* saved_tile, int is_bf16, const void* w_hh_t_bf16,
                       int64_t tiles, int64_t T, int64_t H, void* dg_tile, void* stream_) {
   using namespace seld;
   DeviceState* st = current_state();

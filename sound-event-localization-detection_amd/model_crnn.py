@@ -27,7 +27,12 @@ class ConvBlock(nn.Module):
         self.pool = nn.MaxPool2d(pool_size) if pool_size else None
 
     def forward(self, x):
-        x = self.act(self.bn(self.conv(x)))
+        x = self.conv(x)
+        if x.is_cuda:
+            import seld_convtail
+            if seld_convtail.applicable(self, x):           # fused BN -> ReLU -> pool (csrc/convtail.hip)
+                return seld_convtail.conv_tail(self, x)
+        x = self.act(self.bn(x))
         return x if self.pool is None else self.pool(x)
 
 

@@ -46,9 +46,9 @@ class _BiGRULayer(torch.autograd.Function):
         b, t, _ = y.shape
         h = HIDDEN
         with torch.autocast(device_type="cuda", enabled=False):
-            dg = seld_native.gru_backward(dy.to(y.dtype), saved, w_hh)              # [B,T,2,4,H]
-            dgi = dg[:, :, :, :3].reshape(b * t, 6 * h)                           # d/d(gi), both directions
-            dgh = torch.cat((dg[:, :, :, :2], dg[:, :, :, 3:]), dim=3).reshape(b, t, 2, 3 * h)
+            dgi, dgh = seld_native.gru_backward(dy.to(y.dtype), saved, w_hh, split=True)   # [B,T,2,3,H] each
+            dgi = dgi.reshape(b * t, 6 * h)                                       # d/d(gi), both directions
+            dgh = dgh.reshape(b, t, 2, 3 * h)                                     # d/d(gh)
             x2 = xc.reshape(b * t, -1)
             dx = (dgi @ w_ih.to(cdt)).view_as(xc)
             dw_ih = (dgi.t() @ x2).float()

@@ -62,6 +62,11 @@ def _declare(lib):
     lib.seld_softmax_mse_workspace_bytes.restype = _i64
     lib.seld_softmax_mse_workspace_bytes.argtypes = []
     lib.seld_softmax_mse.argtypes = [_ptr, _int, _ptr, _ptr, _i64, _int, ctypes.c_float, _ptr, _ptr, _ptr, _ptr]
+    lib.seld_conv_tail_workspace_floats.restype = _i64
+    lib.seld_conv_tail_workspace_floats.argtypes = [_int]
+    lib.seld_conv_tail_forward.argtypes = [_ptr, _int, _i64, _int, _int, _ptr, _ptr, _ptr, _ptr, ctypes.c_float,
+                                           ctypes.c_float, _int, _ptr, _ptr, _ptr, _ptr, _ptr]
+    lib.seld_conv_tail_backward.argtypes = [_ptr, _ptr, _int, _i64, _int, _int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]
     lib.seld_gru_tile_rows.restype = _i64
     lib.seld_gru_tile_rows.argtypes = []
     lib.seld_gru_forward.argtypes = [_ptr, _int, _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr]
@@ -318,27 +323,84 @@ def softmax_mse(logits: torch.Tensor, labels: torch.Tensor, grad_scale: float | 
     return loss[0], grad
 
 
+# --------------------------------------------------------------------------- CNN block tail (BN + ReLU + pool)
+
+def conv_tail_supported(channels: int) -> bool:
+    return channels % 8 == 0 and 256 % (channels // 8) == 0
+
+
+def _tail_view(x: torch.Tensor):
+    """4-D activation in channels-last memory order -> (rows, C); raises when the memory order is anything else."""
+    if x.dim() != 4 or not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16):
+        raise SeldNativeError("conv_tail: x must be a 4-D GPU tensor of float32 or bfloat16")
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        raise SeldNativeError("conv_tail: x must be in channels-last memory order")
+    b, c, t, f = x.shape
+    return b * t * f, c
+
+
+def conv_tail_forward(x, weight, bias, running_mean, running_var, momentum, eps, training, pool):
+    """model_crnn.py:5-17 after the convolution: BatchNorm2d -> ReLU -> MaxPool2d((1, pool)) on a channels-last
+    [B, C, T, F] activation.  Returns (y [B, C, T, F // pool] channels-last, mean_invstd [2, C], scale_shift [2, C])."""
+    rows, c = _tail_view(x)
+    b, _, t, f = x.shape
+    if f % pool:
+        raise ValueError("conv_tail: the frequency extent must be a multiple of the pool width")
+    index = ensure_init(x.device)
+    y = torch.empty((b, c, t, f // pool), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    stats = torch.empty((2, 2, c), dtype=torch.float32, device=x.device)
+    lib = load_library()
+    ws = torch.empty(lib.seld_conv_tail_workspace_floats(c), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(index):
+        check(lib.seld_conv_tail_forward(_p(x), int(x.dtype == torch.bfloat16), rows, c, pool, _p(weight), _p(bias),
+                                         _p(running_mean), _p(running_var), float(momentum), float(eps), int(training),
+                                         _p(y), _p(stats[0]), _p(stats[1]), _p(ws), _stream_ptr(x.device)),
+              "seld_conv_tail_forward")
+    return y, stats[0], stats[1]
+
+
+def conv_tail_backward(x, dy, mean_invstd, scale_shift, pool):
+    """-> (dx like x, dweight [C] fp32, dbias [C] fp32)."""
+    rows, c = _tail_view(x)
+    if dy.dtype != x.dtype or not dy.is_contiguous(memory_format=torch.channels_last):
+        dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+    index = ensure_init(x.device)
+    dx = torch.empty_like(x, memory_format=torch.channels_last)
+    dwb = torch.empty((2, c), dtype=torch.float32, device=x.device)
+    lib = load_library()
+    ws = torch.empty(lib.seld_conv_tail_workspace_floats(c), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(index):
+        check(lib.seld_conv_tail_backward(_p(x), _p(dy), int(x.dtype == torch.bfloat16), rows, c, pool, _p(mean_invstd),
+                                          _p(scale_shift), _p(dx), _p(dwb[0]), _p(dwb[1]), _p(ws),
+                                          _stream_ptr(x.device)), "seld_conv_tail_backward")
+    return dx, dwb[0], dwb[1]
+
+
 # --------------------------------------------------------------------------- GRU recurrence
 
-GRU_TILE = 16
+GRU_TILE = 8          # sequences per workgroup (seld_gru_tile_rows(); the MFMA's other 8 columns are padding)
 GRU_H = 256
 
 
 def to_tile(x: torch.Tensor, ns: int) -> torch.Tensor:
-    """[B, T, 2, ns, 256] -> the kernels' tile layout [tiles, T, 2, 8, 2, ns, 4, 16, 4] (batch zero-padded to
-    whole 16-sequence tiles).  unit u = 32*w + 16*s + 4*q + i, row b = 16*tile + c."""
+    """[B, T, 2, ns, 256] -> the kernels' tile layout [tiles, T, 2, 8(w), ns, 4(q), 2(s), 8(seq), 4(i)] (batch
+    zero-padded to whole 8-sequence tiles).  unit u = 32*w + 16*s + 4*q + i, row b = 8*tile + seq; the last three
+    lane dimensions (q, s, seq) are the wavefront lane q*16 + s*8 + seq."""
     b, t = x.shape[0], x.shape[1]
     tiles = (b + GRU_TILE - 1) // GRU_TILE
     if tiles * GRU_TILE != b:
         x = torch.cat((x, x.new_zeros((tiles * GRU_TILE - b,) + tuple(x.shape[1:]))), dim=0)
-    x = x.reshape(tiles, GRU_TILE, t, 2, ns, 8, 2, 4, 4)             # tile, c, T, dir, slot, w, s, q, i
-    return x.permute(0, 2, 3, 5, 6, 4, 7, 1, 8).contiguous()         # tile, T, dir, w, s, slot, q, c, i
+    x = x.reshape(tiles, GRU_TILE, t, 2, ns, 8, 2, 4, 4)             # tile, seq, T, dir, slot, w, s, q, i
+    return x.permute(0, 2, 3, 5, 4, 7, 6, 1, 8).contiguous()         # tile, T, dir, w, slot, q, s, seq, i
 
 
-def from_tile(x: torch.Tensor, batch: int) -> torch.Tensor:
-    """Inverse of to_tile: [tiles, T, 2, 8, 2, ns, 4, 16, 4] -> [batch, T, 2, ns, 256]."""
-    tiles, t, ns = x.shape[0], x.shape[1], x.shape[5]
-    y = x.permute(0, 7, 1, 2, 5, 3, 4, 6, 8).reshape(tiles * GRU_TILE, t, 2, ns, GRU_H)
+def from_tile(x: torch.Tensor, batch: int, slots=None) -> torch.Tensor:
+    """Inverse of to_tile: [tiles, T, 2, 8, ns, 4, 2, 8, 4] -> [batch, T, 2, ns', 256]; ``slots`` picks / reorders
+    slots before the copy (one pass instead of a full un-tile followed by slicing)."""
+    if slots is not None:
+        x = x[:, :, :, :, list(slots)]
+    tiles, t, ns = x.shape[0], x.shape[1], x.shape[4]
+    y = x.permute(0, 7, 1, 2, 4, 3, 6, 5, 8).reshape(tiles * GRU_TILE, t, 2, ns, GRU_H)
     return y[:batch]
 
 
@@ -359,7 +421,8 @@ def gru_forward(gi: torch.Tensor, w_hh: torch.Tensor, b_hn: torch.Tensor, need_s
     if tuple(bias.shape) != (2, h):
         raise ValueError("gru_forward: b_hn must be [2, H]")
     y = torch.empty((tiles * GRU_TILE, t, 2 * h), dtype=gi.dtype, device=gi.device)
-    saved = torch.empty((tiles, t, 2, 8, 2, 5, 4, GRU_TILE, 4), dtype=torch.float32, device=gi.device) \
+    saved_dtype = torch.float16 if gi.dtype == torch.bfloat16 else torch.float32      # see include/seld_hip.h
+    saved = torch.empty((tiles, t, 2, 8, 5, 4, 2, GRU_TILE, 4), dtype=saved_dtype, device=gi.device) \
         if need_saved else None
     with torch.cuda.device(index):
         check(load_library().seld_gru_forward(_p(gi_tile), int(gi.dtype == torch.bfloat16), _p(w), _p(bias), tiles, t,
@@ -367,18 +430,23 @@ def gru_forward(gi: torch.Tensor, w_hh: torch.Tensor, b_hn: torch.Tensor, need_s
     return y[:b], saved
 
 
-def gru_backward(dy: torch.Tensor, saved: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
-    """dy [B, T, 2H] -> dg [B, T, 2, 4, H] (da_r, da_z, da_n, da_n*r), dtype of dy."""
+def gru_backward(dy: torch.Tensor, saved: torch.Tensor, w_hh: torch.Tensor, split: bool = False):
+    """dy [B, T, 2H] -> dg [B, T, 2, 4, H] (da_r, da_z, da_n, da_n*r), dtype of dy; ``split``: return instead
+    (dgi [B, T, 2, 3, H] = slots (0, 1, 2), dgh [B, T, 2, 3, H] = slots (0, 1, 3)), each un-tiled in one pass."""
     b, t, h2 = dy.shape
     h = h2 // 2
     index = ensure_init(dy.device)
+    if saved.dtype != (torch.float16 if dy.dtype == torch.bfloat16 else torch.float32):
+        raise ValueError("gru_backward: saved activations do not belong to a forward pass of this dtype")
     dy_tile = to_tile(dy.reshape(b, t, 2, 1, h), 1)
     tiles = dy_tile.shape[0]
     w_t = w_hh.to(torch.bfloat16).transpose(1, 2).contiguous()            # [2, H, 3H]
-    dg_tile = torch.empty((tiles, t, 2, 8, 2, 4, 4, GRU_TILE, 4), dtype=dy.dtype, device=dy.device)
+    dg_tile = torch.empty((tiles, t, 2, 8, 4, 4, 2, GRU_TILE, 4), dtype=dy.dtype, device=dy.device)
     with torch.cuda.device(index):
         check(load_library().seld_gru_backward(_p(dy_tile), _p(saved), int(dy.dtype == torch.bfloat16), _p(w_t),
                                                tiles, t, h, _p(dg_tile), _stream_ptr(dy.device)), "seld_gru_backward")
+    if split:
+        return from_tile(dg_tile, b, (0, 1, 2)), from_tile(dg_tile, b, (0, 1, 3))
     return from_tile(dg_tile, b)
 
 

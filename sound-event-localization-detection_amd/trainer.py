@@ -84,6 +84,9 @@ def prepare_model_for_device(model, device):
     if device.type == "cuda" and getattr(config, "CHANNELS_LAST", True):
         model = model.to(memory_format=torch.channels_last)
     SeldGRU.fused_enabled = bool(getattr(config, "FUSED_GRU", True))
+    if device.type == "cuda":
+        import seld_convtail
+        seld_convtail.enabled = bool(getattr(config, "FUSED_CONV_TAIL", True))
     SMRSELDLoss.fused_enabled = bool(getattr(config, "FUSED_LOSS", True))
     return model
 

@@ -35,6 +35,22 @@ def timeit(fn):
 y, saved = seld_native.gru_forward(gi, w, bn, True)
 t_f = timeit(lambda: seld_native.gru_forward(gi, w, bn, True))
 t_b = timeit(lambda: seld_native.gru_backward(dy, saved, w))
+# kernel-only timings: pre-tiled operands straight through the C ABI
+lib = seld_native.load_library()
+P = seld_native._p
+gi_tile = seld_native.to_tile(gi.reshape(B, T, 2, 3, H), 3)
+tiles = gi_tile.shape[0]
+wb = w.to(torch.bfloat16).contiguous()
+wt = w.to(torch.bfloat16).transpose(1, 2).contiguous()
+yk = torch.empty((tiles * 8, T, 2 * H), dtype=torch.bfloat16, device=dev)
+dy_tile = seld_native.to_tile(dy.reshape(B, T, 2, 1, H), 1)
+dg_tile = torch.empty((tiles, T, 2, 8, 4, 4, 2, 8, 4), dtype=torch.bfloat16, device=dev)
+st = seld_native._stream_ptr(dev)
+k_f = timeit(lambda: lib.seld_gru_forward(P(gi_tile), 1, P(wb), P(bn), tiles, T, H, P(yk), P(saved), st))
+k_i = timeit(lambda: lib.seld_gru_forward(P(gi_tile), 1, P(wb), P(bn), tiles, T, H, P(yk), None, st))
+k_b = timeit(lambda: lib.seld_gru_backward(P(dy_tile), P(saved), 1, P(wt), tiles, T, H, P(dg_tile), st))
+print(f"kernels only: forward {k_f * 1e3:.0f} us ({k_f * 1e3 / T:.2f} us/step)  forward(no save) {k_i * 1e3:.0f} us "
+      f"({k_i * 1e3 / T:.2f} us/step)  backward {k_b * 1e3:.0f} us ({k_b * 1e3 / T:.2f} us/step)")
 flop = 2 * B * T * 2 * H * 3 * H * 2          # per kernel (both directions)
 print(f"gru B={B} T={T}: forward {t_f * 1e3:.0f} us ({t_f * 1e3 / T:.2f} us/step, {flop / t_f / 1e9:.1f} TFLOP/s) "
       f"backward {t_b * 1e3:.0f} us ({t_b * 1e3 / T:.2f} us/step)")
