@@ -161,19 +161,22 @@ int seld_conv_tail_backward(const void* x, const void* dy, int is_bf16, int64_t 
  *                    (b_hh[0:2H]) must ALREADY be added in (they commute with the sigmoid argument).
  *   w_hh       [2][3H][H] bf16;   b_hn [2][H] fp32 (= b_hh[2H:3H] per direction);   h0 = 0
  *   y          [tiles*8][T][2H] natural layout (h_t; forward direction in [..., :H]), dtype of gi
- *   saved_tile NS=5  r, z, n, (W_hn h + b_hn), h per step for the backward pass, or NULL; fp32 when gi is
- *                    fp32, IEEE fp16 when is_bf16 (O(1) values: 8x finer than bf16 at half of fp32's bytes --
- *                    the recurrence is bound by one CU's load/store path)
+ *   saved_tile       r, z, n, (W_hn h + b_hn) per step for the backward pass, or NULL: 2 pair-slots (r|z, n|gh_n),
+ *                    i.e. [tile][t][dir][w(8)][2][lane(64)][2][4]; fp32 when gi is fp32, IEEE fp16 when is_bf16
+ *                    (O(1) values: 8x finer than bf16 at half of fp32's bytes -- the recurrence is bound by one
+ *                    CU's load/store path).  Opaque to the caller: tiles*T*2*8*2*64*8 elements.
  * MFMA bf16 operands, fp32 accumulation, fp32 gates and state. */
 int64_t seld_gru_tile_rows(void);
 int seld_gru_forward(const void* gi_tile, int is_bf16, const void* w_hh_bf16, const float* b_hn, int64_t tiles,
                      int64_t T, int64_t H, void* y, void* saved_tile, void* stream);
 
-/* Backward of the recurrence.  dy_tile NS=1 (dtype of y), w_hh_t [2][H][3H] bf16 (W_hh transposed).
- * dg_tile NS=4 (dtype of y): da_r, da_z, da_n, da_n*r -- the first three are d/d(gi); slots (0, 1, 3) are
+/* Backward of the recurrence.  dy_tile NS=1 (dtype of y), y = the forward output (all tiles*8 rows),
+ * w_hh_t [2][H][3H] bf16 (W_hh transposed).
+ * dg_tile (dtype of y): da_r, da_z, da_n, da_n*r as 2 pair-slots (da_r|da_z, da_n|da_n*r), i.e.
+ * [tile][t][dir][w(8)][2][q(4)][s(2)][seq(8)][2][i(4)] -- the first three are d/d(gi); (da_r, da_z, da_n*r) are
  * d/d(gh), from which the caller forms dW_hh = dgh^T h_prev, db_hh, and with gi's GEMM dW_ih, db_ih, dx. */
-int seld_gru_backward(const void* dy_tile, const void* saved_tile, int is_bf16, const void* w_hh_t_bf16,
-                      int64_t tiles, int64_t T, int64_t H, void* dg_tile, void* stream);
+int seld_gru_backward(const void* dy_tile, const void* saved_tile, const void* y, int is_bf16,
+                      const void* w_hh_t_bf16, int64_t tiles, int64_t T, int64_t H, void* dg_tile, void* stream);
 
 #ifdef __cplusplus
 }

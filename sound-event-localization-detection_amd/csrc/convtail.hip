@@ -33,6 +33,7 @@ namespace seld {
 constexpr int kTailThreads = 256;
 constexpr int kTailStatBlocks = 1024;    // partial-sum rows per statistic (4 blocks per CU)
 constexpr int kFinalChannels = 16;       // channels per finalise block
+constexpr int kFinalThreads = 1024;      // 32 (statistic, channel) items x 32 partial rows in flight
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_stats_kernel(const void* __
 // update the running statistics exactly like nn.BatchNorm2d in training mode (biased variance for the
 // normalisation, unbiased for running_var, momentum blend).  training == 0: coefficients from the running stats.
 template <typename T>
-__global__ __launch_bounds__(kTailThreads) void tail_stats_final_kernel(const void* __restrict__ x, long rows, int C,
+__global__ __launch_bounds__(kFinalThreads) void tail_stats_final_kernel(const void* __restrict__ x, long rows, int C,
                                                                         const float* __restrict__ partials, int nblocks,
                                                                         const float* __restrict__ weight,
                                                                         const float* __restrict__ bias,
@@ -161,19 +162,21 @@ __global__ __launch_bounds__(kTailThreads) void tail_stats_final_kernel(const vo
                                                                         float momentum, float eps, int training,
                                                                         float* __restrict__ mean_invstd /* [2][C] */,
                                                                         float* __restrict__ scale_shift /* [2][C] */) {
-  __shared__ double red[kTailThreads];
+  __shared__ double red[kFinalThreads];
   const int tid = threadIdx.x;
   const int item = tid & 31;                       // (statistic, channel-in-block)
   const int s = item >> 4, ch = blockIdx.x * kFinalChannels + (item & 15);
-  const int lane_row = tid >> 5;                   // 8 partial rows in parallel
+  const int lane_row = tid >> 5;                   // 32 partial rows in parallel, 8 loads in flight each
   double sum = 0.0;
-  if (training && ch < C)
-    for (int b = lane_row; b < nblocks; b += kTailThreads / 32)
+  if (training && ch < C) {
+#pragma unroll 8
+    for (int b = lane_row; b < nblocks; b += kFinalThreads / 32)
       sum += static_cast<double>(partials[(static_cast<long>(s) * nblocks + b) * C + ch]);
+  }
   red[tid] = sum;
   __syncthreads();
   if (tid < 32) {
-    for (int k = 1; k < kTailThreads / 32; ++k) sum += red[tid + 32 * k];
+    for (int k = 1; k < kFinalThreads / 32; ++k) sum += red[tid + 32 * k];
     red[tid] = sum;
   }
   __syncthreads();
@@ -320,26 +323,28 @@ __global__ __launch_bounds__(kTailThreads) void tail_bwd_reduce_kernel(const voi
 
 // dweight = sum dz xhat, dbias = sum dz; coefficients of dx = a dz + p + q x  with
 //   q = -a * mean(dz xhat) * invstd,  p = -a * mean(dz) - q * mean_x.
-__global__ __launch_bounds__(kTailThreads) void tail_bwd_final_kernel(long rows, int C,
+__global__ __launch_bounds__(kFinalThreads) void tail_bwd_final_kernel(long rows, int C,
                                                                       const float* __restrict__ partials, int nblocks,
                                                                       const float* __restrict__ scale_shift,
                                                                       const float* __restrict__ mean_invstd,
                                                                       float* __restrict__ dweight,
                                                                       float* __restrict__ dbias,
                                                                       float* __restrict__ coef /* [2][C] p, q */) {
-  __shared__ double red[kTailThreads];
+  __shared__ double red[kFinalThreads];
   const int tid = threadIdx.x;
   const int item = tid & 31;
   const int s = item >> 4, ch = blockIdx.x * kFinalChannels + (item & 15);
   const int lane_row = tid >> 5;
   double sum = 0.0;
-  if (ch < C)
-    for (int b = lane_row; b < nblocks; b += kTailThreads / 32)
+  if (ch < C) {
+#pragma unroll 8
+    for (int b = lane_row; b < nblocks; b += kFinalThreads / 32)
       sum += static_cast<double>(partials[(static_cast<long>(s) * nblocks + b) * C + ch]);
+  }
   red[tid] = sum;
   __syncthreads();
   if (tid < 32) {
-    for (int k = 1; k < kTailThreads / 32; ++k) sum += red[tid + 32 * k];
+    for (int k = 1; k < kFinalThreads / 32; ++k) sum += red[tid + 32 * k];
     red[tid] = sum;
   }
   __syncthreads();
@@ -454,10 +459,10 @@ int seld_conv_tail_forward(const void* x, int is_bf16, int64_t rows, int C, int 
                             static_cast<long>(rows), C, workspace);
   }
   const dim3 fgrid((C + kFinalChannels - 1) / kFinalChannels);
-  if (is_bf16) hipLaunchKernelGGL(tail_stats_final_kernel<__hip_bfloat16>, fgrid, dim3(kTailThreads), 0, stream, x,
+  if (is_bf16) hipLaunchKernelGGL(tail_stats_final_kernel<__hip_bfloat16>, fgrid, dim3(kFinalThreads), 0, stream, x,
                                   static_cast<long>(rows), C, workspace, nblocks, weight, bias, running_mean,
                                   running_var, momentum, eps, training, mean_invstd, scale_shift);
-  else hipLaunchKernelGGL(tail_stats_final_kernel<float>, fgrid, dim3(kTailThreads), 0, stream, x,
+  else hipLaunchKernelGGL(tail_stats_final_kernel<float>, fgrid, dim3(kFinalThreads), 0, stream, x,
                           static_cast<long>(rows), C, workspace, nblocks, weight, bias, running_mean, running_var,
                           momentum, eps, training, mean_invstd, scale_shift);
   const long out_rows = rows / pool;
@@ -488,7 +493,7 @@ int seld_conv_tail_backward(const void* x, const void* dy, int is_bf16, int64_t 
   do {                                                                                                           \
     hipLaunchKernelGGL((tail_bwd_reduce_kernel<T, P>), dim3(nblocks), dim3(kTailThreads), 0, stream, x, dy,      \
                        out_rows, C, scale_shift, mean_invstd, workspace);                                        \
-    hipLaunchKernelGGL(tail_bwd_final_kernel, dim3((C + kFinalChannels - 1) / kFinalChannels), dim3(kTailThreads), \
+    hipLaunchKernelGGL(tail_bwd_final_kernel, dim3((C + kFinalChannels - 1) / kFinalChannels), dim3(kFinalThreads), \
                        0, stream, static_cast<long>(rows), C, workspace, nblocks, scale_shift, mean_invstd,      \
                        dweight, dbias, coef);                                                                    \
     hipLaunchKernelGGL((tail_bwd_apply_kernel<T, P>), dim3(tail_grid(st, out_rows, C)), dim3(kTailThreads), 0,   \

@@ -108,6 +108,13 @@ __device__ __forceinline__ void unpack_saved(const uint2& v, float (&f)[4]) {
   f[3] = static_cast<float>(b[1]);
 }
 
+// Two 4-unit groups of one lane stored side by side (one 16-byte access in the bf16 build): the CU's store path is
+// ISSUE-bound (MI355X_MICROARCH.md, "store-ISSUE-bound ... 8x dwordx4 halves it"), so per step the saved
+// activations go out as 2 stores (r|z, n|gh_n) and the gate gradients as 2 (da_r|da_z, da_n|da_n*r).
+template <typename V> struct Pair { V a, b; };
+template <> struct alignas(16) Pair<uint2> { uint2 a, b; };
+template <> struct alignas(16) Pair<float4> { float4 a, b; };
+
 // ---- private "tile" layout of every per-step tensor the kernels stream (gi, saved gates, dy, dg) --------
 // Lane (q = lane>>4, c = lane&15) of wavefront w owns sequence (c & 7) of its 8-sequence tile and the 4 units
 // 32w + 16(c>>3) + 4q .. +3.  Storing the 4-unit group of lane `lane` at
@@ -125,7 +132,7 @@ struct GruFwdArgs {
   const __hip_bfloat16* w_hh;   // [2][3H][H]
   const float* b_hn;     // [2][H]    recurrent bias of the n gate
   void* y;               // [tiles*8][T][2H]  natural layout (what the next layer's GEMM reads), dtype T
-  void* saved;           // tile layout, NS = 5 (r, z, n, gh_n, h), SavedVec<T> groups (nullptr: inference)
+  void* saved;           // tile layout, NS = 2 pairs (r|z, n|gh_n) of SavedVec<T> groups (nullptr: inference)
   long tiles, T;
 };
 
@@ -149,7 +156,8 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
   const float* bh = a.b_hn + dir * kH;
   const V4* gi = static_cast<const V4*>(a.gi);
   T* y = static_cast<T*>(a.y);
-  SV* saved = static_cast<SV*>(a.saved);
+  typedef Pair<SV> SP;
+  SP* saved = static_cast<SP*>(a.saved);
   const long b = tile * kSeqs + seq;       // this lane's sequence (natural-layout row)
 
   float bias_n[4], h_prev[4];
@@ -172,7 +180,7 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
   auto step = [&](long t, V4 (&g)[3]) {
     const long tt = time_of(t);
     const int cur = static_cast<int>(t & 1), nxt = cur ^ 1;
-    SV* const save_base = kSave ? saved + tile_group(tile, a.T, tt, dir, wave, 5, 0, lane) : nullptr;
+    SP* const save_base = kSave ? saved + tile_group(tile, a.T, tt, dir, wave, 2, 0, lane) : nullptr;
     float gir[4], giz[4], gin[4];
     unpack4(g[0], gir);                    // gi already holds b_ih + b_hh for the r and z gates
     unpack4(g[1], giz);
@@ -235,17 +243,13 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
       *reinterpret_cast<V4*>(y + (b * a.T + tt) * (2 * kH) + dir * kH + unit0) = yv;
     }
     if (kSave) {
-      SV v;
-      pack_saved(rr, v);
+      SP v;                                // h itself is not saved: the backward pass reads h_{t-1} from y
+      pack_saved(rr, v.a);
+      pack_saved(zz, v.b);
       save_base[0] = v;
-      pack_saved(zz, v);
+      pack_saved(nn, v.a);
+      pack_saved(gg, v.b);
       save_base[64] = v;
-      pack_saved(nn, v);
-      save_base[128] = v;
-      pack_saved(gg, v);
-      save_base[192] = v;
-      pack_saved(hh, v);
-      save_base[256] = v;
     }
     __syncthreads();
     if (kLdsY) {
@@ -289,6 +293,9 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs 
           *reinterpret_cast<const bf16x8*>(w + static_cast<long>(2 * kH + unit) * kH + k0);
     }
   }
+#ifdef SELD_GRU_SKEW
+  if (wave < 4) __builtin_amdgcn_s_setprio(SELD_GRU_SKEW);   // experiment: de-phase the two waves of a SIMD
+#endif
   // rows 8..15 of both h tiles are never written again: the padding columns of every MFMA stay zero
   for (int i = tid; i < 2 * kRows * kHPitch; i += kGruThreads) hbuf[i] = __float2bfloat16(0.0f);
   __syncthreads();
@@ -298,15 +305,16 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs 
 
 struct GruBwdArgs {
   const void* dy;        // tile layout, NS = 1, dtype T
-  const void* saved;     // tile layout, NS = 5 (r, z, n, gh_n, h), SavedVec<T> groups
+  const void* saved;     // tile layout, NS = 2 pairs (r|z, n|gh_n) of SavedVec<T> groups
+  const void* y;         // [tiles*8][T][2H] the forward output (h_t), natural layout, dtype T
   const __hip_bfloat16* w_hh_t;   // [2][H][3H]   W_hh transposed per direction
-  void* dg;              // tile layout, NS = 4 (da_r, da_z, da_n, da_n * r), dtype T
+  void* dg;              // tile layout, NS = 2 pairs (da_r|da_z, da_n|da_n*r), dtype T
   long tiles, T;
 };
 
 template <typename T> struct GruStepIn {
-  typename SavedVec<T>::type r, z, n, g, hp;
-  typename Vec4<T>::type d;
+  Pair<typename SavedVec<T>::type> rz, ng;
+  typename Vec4<T>::type hp, d;
 };
 
 // dh_prev^T = W_hh^T dgh^T : M = hidden units, N = sequence columns; same lane ownership as the forward kernel.
@@ -323,8 +331,12 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
   const int dir = blockIdx.y;
   const long tile = blockIdx.x;
   const V4* dy = static_cast<const V4*>(a.dy);
-  const SV* saved = static_cast<const SV*>(a.saved);
-  V4* dg = static_cast<V4*>(a.dg);
+  typedef Pair<SV> SP;
+  typedef Pair<V4> DP;
+  const SP* saved = static_cast<const SP*>(a.saved);
+  const T* y = static_cast<const T*>(a.y);
+  DP* dg = static_cast<DP*>(a.dg);
+  const long b = tile * kSeqs + seq;
 
   float dh[4];
 #pragma unroll
@@ -334,12 +346,10 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
   auto load_step = [&](long step, GruStepIn<T>& in) {
     const long tt = time_of(step);
     const long tprev = time_of(step > 0 ? step - 1 : 0);      // h_{t-1} of the forward recurrence (unused at step 0)
-    const SV* sp = saved + tile_group(tile, a.T, tt, dir, wave, 5, 0, lane);
-    in.r = sp[0];
-    in.z = sp[64];
-    in.n = sp[128];
-    in.g = sp[192];
-    in.hp = saved[tile_group(tile, a.T, tprev, dir, wave, 5, 4, lane)];
+    const SP* sp = saved + tile_group(tile, a.T, tt, dir, wave, 2, 0, lane);
+    in.rz = sp[0];
+    in.ng = sp[64];
+    in.hp = *reinterpret_cast<const V4*>(y + (b * a.T + tprev) * (2 * kH) + dir * kH + unit0);
     in.d = dy[tile_group(tile, a.T, tt, dir, wave, 1, 0, lane)];
   };
 
@@ -348,11 +358,11 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
   auto step = [&](long t, GruStepIn<T>& in) {
     const long tt = time_of(t);
     float r[4], z[4], n[4], g[4], hp[4], d[4];
-    unpack_saved(in.r, r);
-    unpack_saved(in.z, z);
-    unpack_saved(in.n, n);
-    unpack_saved(in.g, g);
-    unpack_saved(in.hp, hp);
+    unpack_saved(in.rz.a, r);
+    unpack_saved(in.rz.b, z);
+    unpack_saved(in.ng.a, n);
+    unpack_saved(in.ng.b, g);
+    unpack4(in.hp, hp);
     unpack4(in.d, d);
     __builtin_amdgcn_sched_barrier(0);
     load_step(t > 0 ? t - 1 : 0, in);              // unconditional, clamped; pinned ahead of this step's stores
@@ -370,16 +380,14 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
       dghn[i] = da_n[i] * r[i];
       keep[i] = dtot * z[i];
     }
-    V4* const gp = dg + tile_group(tile, a.T, tt, dir, wave, 4, 0, lane);
-    V4 v;
-    pack4(da_r, v);
+    DP* const gp = dg + tile_group(tile, a.T, tt, dir, wave, 2, 0, lane);
+    DP v;
+    pack4(da_r, v.a);
+    pack4(da_z, v.b);
     gp[0] = v;
-    pack4(da_z, v);
+    pack4(da_n, v.a);
+    pack4(dghn, v.b);
     gp[64] = v;
-    pack4(da_n, v);
-    gp[128] = v;
-    pack4(dghn, v);
-    gp[192] = v;
     __hip_bfloat16* drow = dgh + seq * kDghPitch + unit0;
     uint2 pk;
     pack4(da_r, pk);
@@ -452,6 +460,9 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_backward_kernel(GruBwdArgs
       wn_lds[((wave * 2 + s) * 8 + kk) * 64 + lane] =
           *reinterpret_cast<const bf16x8*>(wt + static_cast<long>(unit) * kG + 2 * kH + 32 * kk + 8 * q);
   }
+#ifdef SELD_GRU_SKEW
+  if (wave < 4) __builtin_amdgcn_s_setprio(SELD_GRU_SKEW);
+#endif
   // rows 8..15 (padding columns of the MFMA) stay zero for the whole kernel
   for (int i = tid; i < kRows * kDghPitch; i += kGruThreads) dgh[i] = __float2bfloat16(0.0f);
   __syncthreads();
@@ -490,16 +501,16 @@ int seld_gru_forward(const void* gi_tile, int is_bf16, const void* w_hh_bf16, co
   return kOk;
 }
 
-int seld_gru_backward(const void* dy_tile, const void* saved_tile, int is_bf16, const void* w_hh_t_bf16,
-                      int64_t tiles, int64_t T, int64_t H, void* dg_tile, void* stream_) {
+int seld_gru_backward(const void* dy_tile, const void* saved_tile, const void* y, int is_bf16,
+                      const void* w_hh_t_bf16, int64_t tiles, int64_t T, int64_t H, void* dg_tile, void* stream_) {
   using namespace seld;
   DeviceState* st = current_state();
   if (!st) return kErrNotInitialised;
   if (H != kH) return fail(kErrUnsupported, "seld_gru_backward: built for hidden size 256 (config.py:45)");
   if (tiles <= 0 || T <= 0) return fail(kErrInvalidArgument, "seld_gru_backward: tiles and T must be positive");
-  if (!dy_tile || !saved_tile || !w_hh_t_bf16 || !dg_tile)
+  if (!dy_tile || !saved_tile || !y || !w_hh_t_bf16 || !dg_tile)
     return fail(kErrInvalidArgument, "seld_gru_backward: null pointer");
-  GruBwdArgs a{dy_tile, saved_tile, static_cast<const __hip_bfloat16*>(w_hh_t_bf16), dg_tile, tiles, T};
+  GruBwdArgs a{dy_tile, saved_tile, y, static_cast<const __hip_bfloat16*>(w_hh_t_bf16), dg_tile, tiles, T};
   const dim3 grid(static_cast<unsigned>(tiles), 2);
   const size_t lds = kWnBytes + kRows * kDghPitch * sizeof(__hip_bfloat16);
   hipStream_t stream = static_cast<hipStream_t>(stream_);

@@ -46,22 +46,40 @@ class _BiGRULayer(torch.autograd.Function):
         b, t, _ = y.shape
         h = HIDDEN
         with torch.autocast(device_type="cuda", enabled=False):
-            dgi, dgh = seld_native.gru_backward(dy.to(y.dtype), saved, w_hh, split=True)   # [B,T,2,3,H] each
-            dgi = dgi.reshape(b * t, 6 * h)                                       # d/d(gi), both directions
-            dgh = dgh.reshape(b, t, 2, 3 * h)                                     # d/d(gh)
+            # one un-tiling pass; everything below reads strided views of it (no further copies of the 8000-row
+            # gradient matrices): slots (r, z, n) = d/d(gi), slots (r, z, n*r) = d/d(gh)
+            dg = seld_native.gru_backward(dy.to(y.dtype), saved, y, w_hh)           # [B, T, 2, 4, H]
+            d2 = dg.view(b * t, 2, 4 * h)
             x2 = xc.reshape(b * t, -1)
-            dx = (dgi @ w_ih.to(cdt)).view_as(xc)
-            dw_ih = (dgi.t() @ x2).float()
-            db_ih = dgi.float().sum(dim=0)
+            w = w_ih.to(cdt)
+            dx = d2[:, 0, :3 * h] @ w[:3 * h]
+            dx.addmm_(d2[:, 1, :3 * h], w[3 * h:])
+            dw_ih = torch.cat((d2[:, 0, :3 * h].t() @ x2, d2[:, 1, :3 * h].t() @ x2), dim=0).float()
+            sums = torch.sum(d2, dim=0, dtype=torch.float32)                      # [2, 4H]
+            db_ih = sums[:, :3 * h].reshape(-1)
             # h_{t-1} of the forward recurrence: y shifted by one step in each direction's own time order
             yv = y.view(b, t, 2, h)
             h_prev = torch.zeros_like(yv)
             h_prev[:, 1:, 0] = yv[:, :-1, 0]
             h_prev[:, :-1, 1] = yv[:, 1:, 1]
-            dw_hh = torch.einsum("btdg,btdh->dgh", dgh, h_prev).float()
-            db_hh = dgh.float().sum(dim=(0, 1))
+            full = _reduce_rows(d2, h_prev.view(b * t, 2, h))                     # [2, 4H, H]
+            dw_hh = torch.cat((full[:, :2 * h], full[:, 3 * h:]), dim=1)
+            db_hh = torch.cat((sums[:, :2 * h], sums[:, 3 * h:]), dim=1)
+        dx = dx.view_as(xc)
         return dx.to(dy.dtype) if dx.dtype != dy.dtype and not torch.is_autocast_enabled() else dx, \
             dw_ih.to(w_ih.dtype), db_ih.to(w_ih.dtype), dw_hh.to(w_hh.dtype), db_hh.to(w_hh.dtype)
+
+
+def _reduce_rows(a, c, chunks=8):
+    """sum_n a[n, d, :]^T c[n, d, :] -> [D, Ga, Gc] fp32.  The output is tiny (2 x 1024 x 256) and the reduction
+    long (B*T = 8000 rows): split the rows into chunks so the batched GEMM has enough tiles to fill the GPU,
+    then add the partial products in fp32."""
+    n = a.shape[0]
+    while chunks > 1 and n % chunks:
+        chunks //= 2
+    a = a.view(chunks, n // chunks, a.shape[1], a.shape[2])
+    c = c.view(chunks, n // chunks, c.shape[1], c.shape[2])
+    return torch.einsum("sndg,sndh->sdgh", a, c).float().sum(dim=0)
 
 
 def bigru_forward(module, x):

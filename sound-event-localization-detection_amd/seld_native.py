@@ -70,7 +70,7 @@ def _declare(lib):
     lib.seld_gru_tile_rows.restype = _i64
     lib.seld_gru_tile_rows.argtypes = []
     lib.seld_gru_forward.argtypes = [_ptr, _int, _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr]
-    lib.seld_gru_backward.argtypes = [_ptr, _ptr, _int, _ptr, _i64, _i64, _i64, _ptr, _ptr]
+    lib.seld_gru_backward.argtypes = [_ptr, _ptr, _ptr, _int, _ptr, _i64, _i64, _i64, _ptr, _ptr]
     return lib
 
 
@@ -394,19 +394,25 @@ def to_tile(x: torch.Tensor, ns: int) -> torch.Tensor:
     return x.permute(0, 2, 3, 5, 4, 7, 6, 1, 8).contiguous()         # tile, T, dir, w, slot, q, s, seq, i
 
 
-def from_tile(x: torch.Tensor, batch: int, slots=None) -> torch.Tensor:
-    """Inverse of to_tile: [tiles, T, 2, 8, ns, 4, 2, 8, 4] -> [batch, T, 2, ns', 256]; ``slots`` picks / reorders
-    slots before the copy (one pass instead of a full un-tile followed by slicing)."""
-    if slots is not None:
-        x = x[:, :, :, :, list(slots)]
+def from_tile(x: torch.Tensor, batch: int) -> torch.Tensor:
+    """Inverse of to_tile: [tiles, T, 2, 8, ns, 4, 2, 8, 4] -> [batch, T, 2, ns, 256]."""
     tiles, t, ns = x.shape[0], x.shape[1], x.shape[4]
     y = x.permute(0, 7, 1, 2, 4, 3, 6, 5, 8).reshape(tiles * GRU_TILE, t, 2, ns, GRU_H)
     return y[:batch]
 
 
+def from_pair_tile(x: torch.Tensor, batch: int) -> torch.Tensor:
+    """The pair-slot layout of the backward kernel's output, [tiles, T, 2, 8(w), 2(pair slot), 4(q), 2(s), 8(seq),
+    2(member), 4(i)] -> [batch, T, 2, 4 (slot = 2*pair + member), 256] in one pass."""
+    tiles, t = x.shape[0], x.shape[1]
+    y = x.permute(0, 7, 1, 2, 4, 8, 3, 6, 5, 9).reshape(tiles * GRU_TILE, t, 2, 4, GRU_H)
+    return y[:batch]
+
+
 def gru_forward(gi: torch.Tensor, w_hh: torch.Tensor, b_hn: torch.Tensor, need_saved: bool):
     """gi [B, T, 2, 3H] (fp32 / bf16; must already include b_ih and the r/z part of b_hh), w_hh [2, 3H, H],
-    b_hn [2, H] (n-gate recurrent bias) -> (y [B, T, 2H], saved (tile layout, opaque) or None)."""
+    b_hn [2, H] (n-gate recurrent bias) -> (y [B, T, 2H], saved (tile layout, opaque) or None).  y is a view of
+    the first B rows of a buffer padded to whole 8-sequence tiles."""
     if not gi.is_cuda:
         raise SeldNativeError("gru_forward: tensors must live on the GPU")
     b, t, two, g3 = gi.shape
@@ -422,7 +428,7 @@ def gru_forward(gi: torch.Tensor, w_hh: torch.Tensor, b_hn: torch.Tensor, need_s
         raise ValueError("gru_forward: b_hn must be [2, H]")
     y = torch.empty((tiles * GRU_TILE, t, 2 * h), dtype=gi.dtype, device=gi.device)
     saved_dtype = torch.float16 if gi.dtype == torch.bfloat16 else torch.float32      # see include/seld_hip.h
-    saved = torch.empty((tiles, t, 2, 8, 5, 4, 2, GRU_TILE, 4), dtype=saved_dtype, device=gi.device) \
+    saved = torch.empty((tiles, t, 2, 8, 2, 64, 2, 4), dtype=saved_dtype, device=gi.device) \
         if need_saved else None
     with torch.cuda.device(index):
         check(load_library().seld_gru_forward(_p(gi_tile), int(gi.dtype == torch.bfloat16), _p(w), _p(bias), tiles, t,
@@ -430,24 +436,27 @@ def gru_forward(gi: torch.Tensor, w_hh: torch.Tensor, b_hn: torch.Tensor, need_s
     return y[:b], saved
 
 
-def gru_backward(dy: torch.Tensor, saved: torch.Tensor, w_hh: torch.Tensor, split: bool = False):
-    """dy [B, T, 2H] -> dg [B, T, 2, 4, H] (da_r, da_z, da_n, da_n*r), dtype of dy; ``split``: return instead
-    (dgi [B, T, 2, 3, H] = slots (0, 1, 2), dgh [B, T, 2, 3, H] = slots (0, 1, 3)), each un-tiled in one pass."""
+def gru_backward(dy: torch.Tensor, saved: torch.Tensor, y: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
+    """dy [B, T, 2H], the forward's (saved, y) -> dg [B, T, 2, 4, H] (da_r, da_z, da_n, da_n*r), dtype of dy."""
     b, t, h2 = dy.shape
     h = h2 // 2
     index = ensure_init(dy.device)
     if saved.dtype != (torch.float16 if dy.dtype == torch.bfloat16 else torch.float32):
         raise ValueError("gru_backward: saved activations do not belong to a forward pass of this dtype")
+    if y.dtype != dy.dtype or tuple(y.shape) != (b, t, h2):
+        raise ValueError("gru_backward: y must be the forward output matching dy")
     dy_tile = to_tile(dy.reshape(b, t, 2, 1, h), 1)
     tiles = dy_tile.shape[0]
+    if tiles * GRU_TILE != b:               # the kernel reads whole tiles of y (h_{t-1}); pad rows are never used
+        y = torch.cat((y, y.new_zeros((tiles * GRU_TILE - b, t, h2))), dim=0)
+    y = y.contiguous()
     w_t = w_hh.to(torch.bfloat16).transpose(1, 2).contiguous()            # [2, H, 3H]
-    dg_tile = torch.empty((tiles, t, 2, 8, 4, 4, 2, GRU_TILE, 4), dtype=dy.dtype, device=dy.device)
+    dg_tile = torch.empty((tiles, t, 2, 8, 2, 4, 2, GRU_TILE, 2, 4), dtype=dy.dtype, device=dy.device)
     with torch.cuda.device(index):
-        check(load_library().seld_gru_backward(_p(dy_tile), _p(saved), int(dy.dtype == torch.bfloat16), _p(w_t),
-                                               tiles, t, h, _p(dg_tile), _stream_ptr(dy.device)), "seld_gru_backward")
-    if split:
-        return from_tile(dg_tile, b, (0, 1, 2)), from_tile(dg_tile, b, (0, 1, 3))
-    return from_tile(dg_tile, b)
+        check(load_library().seld_gru_backward(_p(dy_tile), _p(saved), _p(y), int(dy.dtype == torch.bfloat16),
+                                               _p(w_t), tiles, t, h, _p(dg_tile), _stream_ptr(dy.device)),
+              "seld_gru_backward")
+    return from_pair_tile(dg_tile, b)
 
 
 # --------------------------------------------------------------------------- STFT / spatial features

@@ -36,10 +36,8 @@ def test_forward_matches_bf16_aware_oracle(gpu_device, batch, steps):
     y, saved = seld_native.gru_forward(gi.to(gpu_device), torch.stack(w_hh).to(gpu_device), b_hn.to(gpu_device), True)
     ref = ogru.bigru_layer(x, w_ih, b_ih, w_hh, b_hh, exact=False)
     tiles = (batch + 7) // 8
-    assert tuple(y.shape) == (batch, steps, 2 * H) and tuple(saved.shape) == (tiles, steps, 2, 8, 5, 4, 2, 8, 4)
-    # slot 4 of the saved gates is h itself (tile layout round trip)
-    assert saved.dtype == torch.float32 and torch.equal(
-        seld_native.from_tile(saved, batch)[:, :, :, 4].reshape(batch, steps, 2 * H).to(y.dtype), y)
+    assert tuple(y.shape) == (batch, steps, 2 * H) and tuple(saved.shape) == (tiles, steps, 2, 8, 2, 64, 2, 4)
+    assert saved.dtype == torch.float32                     # fp32 build; the bf16 build saves IEEE fp16
     assert (y.cpu() - ref).abs().max().item() <= 2e-3
     exact = ogru.bigru_layer(x, w_ih, b_ih, w_hh, b_hh, exact=True)
     assert (y.cpu() - exact).abs().max().item() <= 3e-2          # bf16 drift of the recurrence
