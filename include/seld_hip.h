@@ -174,9 +174,12 @@ int seld_gru_forward(const void* gi_tile, int is_bf16, const void* w_hh_bf16, co
  * w_hh_t [2][H][3H] bf16 (W_hh transposed).
  * dg_tile (dtype of y): da_r, da_z, da_n, da_n*r as 2 pair-slots (da_r|da_z, da_n|da_n*r), i.e.
  * [tile][t][dir][w(8)][2][q(4)][s(2)][seq(8)][2][i(4)] -- the first three are d/d(gi); (da_r, da_z, da_n*r) are
- * d/d(gh), from which the caller forms dW_hh = dgh^T h_prev, db_hh, and with gi's GEMM dW_ih, db_ih, dx. */
+ * d/d(gh), from which the caller forms dW_hh = dgh^T h_prev and with gi's GEMM dW_ih, dx.
+ * dbias [tiles][2][4][H] fp32: the four slots summed over the tile's sequences and all t (add the tiles for
+ * db_ih = slots (0,1,2) and db_hh = slots (0,1,3)). */
 int seld_gru_backward(const void* dy_tile, const void* saved_tile, const void* y, int is_bf16,
-                      const void* w_hh_t_bf16, int64_t tiles, int64_t T, int64_t H, void* dg_tile, void* stream);
+                      const void* w_hh_t_bf16, int64_t tiles, int64_t T, int64_t H, void* dg_tile, float* dbias,
+                      void* stream);
 
 #ifdef __cplusplus
 }

@@ -309,6 +309,7 @@ struct GruBwdArgs {
   const void* y;         // [tiles*8][T][2H] the forward output (h_t), natural layout, dtype T
   const __hip_bfloat16* w_hh_t;   // [2][H][3H]   W_hh transposed per direction
   void* dg;              // tile layout, NS = 2 pairs (da_r|da_z, da_n|da_n*r), dtype T
+  float* dbias;          // [tiles][2][4][H]  per-tile sums over (sequence, t) of the four dg slots (fp32)
   long tiles, T;
 };
 
@@ -338,9 +339,13 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
   DP* dg = static_cast<DP*>(a.dg);
   const long b = tile * kSeqs + seq;
 
-  float dh[4];
+  float dh[4], bsum[4][4];           // bsum: running sums of da_r, da_z, da_n, da_n*r (the bias gradients)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) dh[i] = 0.0f;
+  for (int i = 0; i < 4; ++i) {
+    dh[i] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bsum[k][i] = 0.0f;
+  }
 
   auto time_of = [&](long step) { return dir == 0 ? step : a.T - 1 - step; };
   auto load_step = [&](long step, GruStepIn<T>& in) {
@@ -379,6 +384,10 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
       da_r[i] = da_n[i] * g[i] * r[i] * (1.0f - r[i]);
       dghn[i] = da_n[i] * r[i];
       keep[i] = dtot * z[i];
+      bsum[0][i] += da_r[i];
+      bsum[1][i] += da_z[i];
+      bsum[2][i] += da_n[i];
+      bsum[3][i] += dghn[i];
     }
     DP* const gp = dg + tile_group(tile, a.T, tt, dir, wave, 2, 0, lane);
     DP v;
@@ -436,6 +445,24 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
   step(a.T - 1, in);
 #pragma unroll 1
   for (long t = a.T - 2; t >= 0; --t) step(t, in);
+
+  // bias gradients: add the 8 sequences of the tile (lanes that differ in c & 7), one float4 per slot and lane group
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = bsum[k][i];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      bsum[k][i] = v;
+    }
+  if (seq == 0) {
+    float* out = a.dbias + ((tile * 2 + dir) * 4) * kH + unit0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      *reinterpret_cast<float4*>(out + k * kH) = make_float4(bsum[k][0], bsum[k][1], bsum[k][2], bsum[k][3]);
+  }
 }
 
 template <typename T>
@@ -502,15 +529,16 @@ int seld_gru_forward(const void* gi_tile, int is_bf16, const void* w_hh_bf16, co
 }
 
 int seld_gru_backward(const void* dy_tile, const void* saved_tile, const void* y, int is_bf16,
-                      const void* w_hh_t_bf16, int64_t tiles, int64_t T, int64_t H, void* dg_tile, void* stream_) {
+                      const void* w_hh_t_bf16, int64_t tiles, int64_t T, int64_t H, void* dg_tile, float* dbias,
+                      void* stream_) {
   using namespace seld;
   DeviceState* st = current_state();
   if (!st) return kErrNotInitialised;
   if (H != kH) return fail(kErrUnsupported, "seld_gru_backward: built for hidden size 256 (config.py:45)");
   if (tiles <= 0 || T <= 0) return fail(kErrInvalidArgument, "seld_gru_backward: tiles and T must be positive");
-  if (!dy_tile || !saved_tile || !y || !w_hh_t_bf16 || !dg_tile)
+  if (!dy_tile || !saved_tile || !y || !w_hh_t_bf16 || !dg_tile || !dbias)
     return fail(kErrInvalidArgument, "seld_gru_backward: null pointer");
-  GruBwdArgs a{dy_tile, saved_tile, y, static_cast<const __hip_bfloat16*>(w_hh_t_bf16), dg_tile, tiles, T};
+  GruBwdArgs a{dy_tile, saved_tile, y, static_cast<const __hip_bfloat16*>(w_hh_t_bf16), dg_tile, dbias, tiles, T};
   const dim3 grid(static_cast<unsigned>(tiles), 2);
   const size_t lds = kWnBytes + kRows * kDghPitch * sizeof(__hip_bfloat16);
   hipStream_t stream = static_cast<hipStream_t>(stream_);

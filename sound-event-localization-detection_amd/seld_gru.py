@@ -45,41 +45,46 @@ class _BiGRULayer(torch.autograd.Function):
         cdt = ctx.cdt
         b, t, _ = y.shape
         h = HIDDEN
+        n = b * t
         with torch.autocast(device_type="cuda", enabled=False):
-            # one un-tiling pass; everything below reads strided views of it (no further copies of the 8000-row
-            # gradient matrices): slots (r, z, n) = d/d(gi), slots (r, z, n*r) = d/d(gh)
-            dg = seld_native.gru_backward(dy.to(y.dtype), saved, y, w_hh)           # [B, T, 2, 4, H]
-            d2 = dg.view(b * t, 2, 4 * h)
-            x2 = xc.reshape(b * t, -1)
-            w = w_ih.to(cdt)
-            dx = d2[:, 0, :3 * h] @ w[:3 * h]
-            dx.addmm_(d2[:, 1, :3 * h], w[3 * h:])
-            dw_ih = torch.cat((d2[:, 0, :3 * h].t() @ x2, d2[:, 1, :3 * h].t() @ x2), dim=0).float()
-            sums = torch.sum(d2, dim=0, dtype=torch.float32)                      # [2, 4H]
-            db_ih = sums[:, :3 * h].reshape(-1)
+            dgi, dghn, dbias = seld_native.gru_backward(dy.to(y.dtype), saved, y, w_hh)
+            dgi2 = dgi.view(n, 6 * h)                                             # d/d(gi), both directions
+            x2 = xc.reshape(n, -1)
+            dx = (dgi2 @ w_ih.to(cdt)).view_as(xc)
+            dw_ih = _tall_product(dgi2, x2)                                       # [6H, In] fp32
+            db_ih = dbias[:, :3].reshape(-1)
+            db_hh = torch.cat((dbias[:, :2], dbias[:, 3:]), dim=1).reshape(2, 3 * h)
             # h_{t-1} of the forward recurrence: y shifted by one step in each direction's own time order
             yv = y.view(b, t, 2, h)
-            h_prev = torch.zeros_like(yv)
+            h_prev = torch.empty_like(yv)
             h_prev[:, 1:, 0] = yv[:, :-1, 0]
             h_prev[:, :-1, 1] = yv[:, 1:, 1]
-            full = _reduce_rows(d2, h_prev.view(b * t, 2, h))                     # [2, 4H, H]
-            dw_hh = torch.cat((full[:, :2 * h], full[:, 3 * h:]), dim=1)
-            db_hh = torch.cat((sums[:, :2 * h], sums[:, 3 * h:]), dim=1)
-        dx = dx.view_as(xc)
+            h_prev[:, 0, 0] = 0
+            h_prev[:, -1, 1] = 0
+            hp = h_prev.view(n, 2, h)
+            g4 = dgi.view(n, 2, 3, h)
+            dn = dghn.view(n, 2, h)
+            # d/d(gh) = (da_r, da_z, da_n * r): the r, z rows straight from dgi (strided view), the n rows from dghn
+            dw_hh = torch.stack([torch.cat((_tall_product(g4[:, d, :2].flatten(1), hp[:, d]),
+                                            _tall_product(dn[:, d], hp[:, d])), dim=0) for d in range(2)], dim=0)
         return dx.to(dy.dtype) if dx.dtype != dy.dtype and not torch.is_autocast_enabled() else dx, \
             dw_ih.to(w_ih.dtype), db_ih.to(w_ih.dtype), dw_hh.to(w_hh.dtype), db_hh.to(w_hh.dtype)
 
 
-def _reduce_rows(a, c, chunks=8):
-    """sum_n a[n, d, :]^T c[n, d, :] -> [D, Ga, Gc] fp32.  The output is tiny (2 x 1024 x 256) and the reduction
-    long (B*T = 8000 rows): split the rows into chunks so the batched GEMM has enough tiles to fill the GPU,
-    then add the partial products in fp32."""
-    n = a.shape[0]
-    while chunks > 1 and n % chunks:
-        chunks //= 2
-    a = a.view(chunks, n // chunks, a.shape[1], a.shape[2])
-    c = c.view(chunks, n // chunks, c.shape[1], c.shape[2])
-    return torch.einsum("sndg,sndh->sdgh", a, c).float().sum(dim=0)
+def _tall_product(a, c, min_tiles=256):
+    """a^T c for tall operands (a [N, G], c [N, K], N = B*T = 8000 rows) -> [G, K] fp32.  When the output is too
+    small to fill the GPU with 128 x 128 tiles the rows are split into chunks multiplied as one batched GEMM
+    (transposed views, no copies) and the partial products are added in fp32."""
+    n, g = a.shape
+    k = c.shape[1]
+    chunks = 1
+    while chunks < 16 and chunks * ((g + 127) // 128) * ((k + 127) // 128) < min_tiles and n % (2 * chunks) == 0:
+        chunks *= 2
+    if chunks == 1:
+        return (a.t() @ c).float()
+    av = a.unflatten(0, (chunks, n // chunks)).transpose(1, 2)                    # [chunks, G, N/chunks] view
+    cv = c.unflatten(0, (chunks, n // chunks))
+    return torch.bmm(av, cv).float().sum(dim=0)
 
 
 def bigru_forward(module, x):

@@ -70,7 +70,7 @@ def _declare(lib):
     lib.seld_gru_tile_rows.restype = _i64
     lib.seld_gru_tile_rows.argtypes = []
     lib.seld_gru_forward.argtypes = [_ptr, _int, _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr]
-    lib.seld_gru_backward.argtypes = [_ptr, _ptr, _ptr, _int, _ptr, _i64, _i64, _i64, _ptr, _ptr]
+    lib.seld_gru_backward.argtypes = [_ptr, _ptr, _ptr, _int, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr]
     return lib
 
 
@@ -401,12 +401,18 @@ def from_tile(x: torch.Tensor, batch: int) -> torch.Tensor:
     return y[:batch]
 
 
-def from_pair_tile(x: torch.Tensor, batch: int) -> torch.Tensor:
+def from_pair_tile(x: torch.Tensor, batch: int):
     """The pair-slot layout of the backward kernel's output, [tiles, T, 2, 8(w), 2(pair slot), 4(q), 2(s), 8(seq),
-    2(member), 4(i)] -> [batch, T, 2, 4 (slot = 2*pair + member), 256] in one pass."""
+    2(member), 4(i)] with slots (da_r|da_z), (da_n|da_n*r) -> (dgi [batch, T, 2, 3, 256] = (da_r, da_z, da_n),
+    dghn [batch, T, 2, 256] = da_n*r), both contiguous: exactly the bytes the host GEMMs read, copied once."""
     tiles, t = x.shape[0], x.shape[1]
-    y = x.permute(0, 7, 1, 2, 4, 8, 3, 6, 5, 9).reshape(tiles * GRU_TILE, t, 2, 4, GRU_H)
-    return y[:batch]
+    src = x.permute(0, 7, 1, 2, 4, 8, 3, 6, 5, 9)          # tile, seq, T, dir, pair, member, w, s, q, i
+    dgi = torch.empty((tiles, GRU_TILE, t, 2, 3, 8, 2, 4, 4), dtype=x.dtype, device=x.device)
+    dghn = torch.empty((tiles, GRU_TILE, t, 2, 8, 2, 4, 4), dtype=x.dtype, device=x.device)
+    dgi[:, :, :, :, 0:2].copy_(src[:, :, :, :, 0])
+    dgi[:, :, :, :, 2].copy_(src[:, :, :, :, 1, 0])
+    dghn.copy_(src[:, :, :, :, 1, 1])
+    return (dgi.view(tiles * GRU_TILE, t, 2, 3, GRU_H)[:batch], dghn.view(tiles * GRU_TILE, t, 2, GRU_H)[:batch])
 
 
 def gru_forward(gi: torch.Tensor, w_hh: torch.Tensor, b_hn: torch.Tensor, need_saved: bool):
@@ -436,8 +442,9 @@ def gru_forward(gi: torch.Tensor, w_hh: torch.Tensor, b_hn: torch.Tensor, need_s
     return y[:b], saved
 
 
-def gru_backward(dy: torch.Tensor, saved: torch.Tensor, y: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
-    """dy [B, T, 2H], the forward's (saved, y) -> dg [B, T, 2, 4, H] (da_r, da_z, da_n, da_n*r), dtype of dy."""
+def gru_backward(dy: torch.Tensor, saved: torch.Tensor, y: torch.Tensor, w_hh: torch.Tensor):
+    """dy [B, T, 2H], the forward's (saved, y) -> (dgi [B, T, 2, 3, H] = (da_r, da_z, da_n), dghn [B, T, 2, H] =
+    da_n*r, both of dy's dtype, dbias [2, 4, H] fp32 = the four slots summed over batch and time)."""
     b, t, h2 = dy.shape
     h = h2 // 2
     index = ensure_init(dy.device)
@@ -452,11 +459,13 @@ def gru_backward(dy: torch.Tensor, saved: torch.Tensor, y: torch.Tensor, w_hh: t
     y = y.contiguous()
     w_t = w_hh.to(torch.bfloat16).transpose(1, 2).contiguous()            # [2, H, 3H]
     dg_tile = torch.empty((tiles, t, 2, 8, 2, 4, 2, GRU_TILE, 2, 4), dtype=dy.dtype, device=dy.device)
+    dbias = torch.empty((tiles, 2, 4, h), dtype=torch.float32, device=dy.device)
     with torch.cuda.device(index):
         check(load_library().seld_gru_backward(_p(dy_tile), _p(saved), _p(y), int(dy.dtype == torch.bfloat16),
-                                               _p(w_t), tiles, t, h, _p(dg_tile), _stream_ptr(dy.device)),
+                                               _p(w_t), tiles, t, h, _p(dg_tile), _p(dbias), _stream_ptr(dy.device)),
               "seld_gru_backward")
-    return from_pair_tile(dg_tile, b)
+    dgi, dghn = from_pair_tile(dg_tile, b)
+    return dgi, dghn, dbias.sum(dim=0) if tiles > 1 else dbias[0]
 
 
 # --------------------------------------------------------------------------- STFT / spatial features

@@ -51,7 +51,8 @@ dg_tile = torch.empty((tiles, T, 2, 8, 2, 4, 2, 8, 2, 4), dtype=torch.bfloat16, 
 st = seld_native._stream_ptr(dev)
 k_f = timeit(lambda: lib.seld_gru_forward(P(gi_tile), 1, P(wb), P(bn), tiles, T, H, P(yk), P(saved), st))
 k_i = timeit(lambda: lib.seld_gru_forward(P(gi_tile), 1, P(wb), P(bn), tiles, T, H, P(yk), None, st))
-k_b = timeit(lambda: lib.seld_gru_backward(P(dy_tile), P(saved), P(yk), 1, P(wt), tiles, T, H, P(dg_tile), st))
+dbias = torch.empty((tiles, 2, 4, H), device=dev)
+k_b = timeit(lambda: lib.seld_gru_backward(P(dy_tile), P(saved), P(yk), 1, P(wt), tiles, T, H, P(dg_tile), P(dbias), st))
 print(f"kernels only: forward {k_f * 1e3:.0f} us ({k_f * 1e3 / T:.2f} us/step)  forward(no save) {k_i * 1e3:.0f} us "
       f"({k_i * 1e3 / T:.2f} us/step)  backward {k_b * 1e3:.0f} us ({k_b * 1e3 / T:.2f} us/step)")
 flop = 2 * B * T * 2 * H * 3 * H * 2          # per kernel (both directions)
