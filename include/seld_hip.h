@@ -181,6 +181,14 @@ int seld_gru_backward(const void* dy_tile, const void* saved_tile, const void* y
                       const void* w_hh_t_bf16, int64_t tiles, int64_t T, int64_t H, void* dg_tile, float* dbias,
                       void* stream);
 
+/* Layout converters for the two calls above (HBM-bound permutes; elem_bytes = 2 for bf16, 4 for fp32).
+ * seld_gru_to_tile: natural src [B][T][2][ns][H] -> tile layout dst (B padded with zeros to whole tiles).
+ * seld_gru_from_pair_tile: the backward kernel's dg_tile -> dgi [B][T][2][3][H] (da_r, da_z, da_n) and
+ * dghn [B][T][2][H] (da_n*r), both contiguous -- what the caller's GEMMs read. */
+int seld_gru_to_tile(const void* src, int elem_bytes, int64_t B, int64_t T, int ns, void* dst, void* stream);
+int seld_gru_from_pair_tile(const void* dg_tile, int elem_bytes, int64_t B, int64_t T, void* dgi, void* dghn,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -496,9 +496,95 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_backward_kernel(GruBwdArgs
   gru_backward_steps<T>(a, wn_lds, dgh, wrz);
 }
 
+// ---- layout converters between the natural [B][T][2][NS][H] tensors of the host GEMMs and the tile layout ----
+// One block per (tile, t, direction): 8 sequences x NS x 64 four-unit groups.  The tile side is accessed as one
+// contiguous run per block; the natural side as 64-byte (bf16) / 128-byte (fp32) pieces of 512-B / 1-KB rows,
+// every byte exactly once.  HBM-bound permutes (read + write of the tensor), replacing strided framework copies.
+template <typename G>
+__global__ __launch_bounds__(256) void gru_to_tile_kernel(const G* __restrict__ src, long B, long T, int ns,
+                                                          G* __restrict__ dst) {
+  const long blk = blockIdx.x;
+  const int dir = static_cast<int>(blk & 1);
+  const long t = (blk >> 1) % T, tile = (blk >> 1) / T;
+  const int groups = 8 * ns * 64;
+  G zero;
+  __builtin_memset(&zero, 0, sizeof(G));
+  for (int g = threadIdx.x; g < groups; g += 256) {
+    const int lane = g & 63, slot = (g >> 6) % ns, w = (g >> 6) / ns;
+    const int seq = lane & 7, s = (lane >> 3) & 1, q = lane >> 4;
+    const long b = tile * kSeqs + seq;
+    const int ug = 8 * w + 4 * s + q;                     // four-unit group along H: units 32w + 16s + 4q ..
+    G v = zero;
+    if (b < B) v = src[(((b * T + t) * 2 + dir) * ns + slot) * 64 + ug];
+    dst[blk * groups + g] = v;
+  }
+}
+
+template <typename G>
+__global__ __launch_bounds__(256) void gru_from_pair_tile_kernel(const Pair<G>* __restrict__ src, long B, long T,
+                                                                 G* __restrict__ dgi, G* __restrict__ dghn) {
+  const long blk = blockIdx.x;
+  const int dir = static_cast<int>(blk & 1);
+  const long t = (blk >> 1) % T, tile = (blk >> 1) / T;
+  for (int g = threadIdx.x; g < 8 * 2 * 64; g += 256) {
+    const int lane = g & 63, ps = (g >> 6) & 1, w = g >> 7;
+    const int seq = lane & 7, s = (lane >> 3) & 1, q = lane >> 4;
+    const long b = tile * kSeqs + seq;
+    if (b >= B) continue;
+    const Pair<G> p = src[blk * (8 * 2 * 64) + g];
+    const int ug = 8 * w + 4 * s + q;
+    const long row = (b * T + t) * 2 + dir;
+    if (ps == 0) {
+      dgi[(row * 3 + 0) * 64 + ug] = p.a;                 // da_r
+      dgi[(row * 3 + 1) * 64 + ug] = p.b;                 // da_z
+    } else {
+      dgi[(row * 3 + 2) * 64 + ug] = p.a;                 // da_n
+      dghn[row * 64 + ug] = p.b;                          // da_n * r
+    }
+  }
+}
+
 }  // namespace seld
 
 extern "C" {
+
+int seld_gru_to_tile(const void* src, int elem_bytes, int64_t B, int64_t T, int ns, void* dst, void* stream_) {
+  using namespace seld;
+  if (!current_state()) return kErrNotInitialised;
+  if (B <= 0 || T <= 0 || ns <= 0) return fail(kErrInvalidArgument, "seld_gru_to_tile: B, T, ns must be positive");
+  if (elem_bytes != 2 && elem_bytes != 4) return fail(kErrUnsupported, "seld_gru_to_tile: 2- or 4-byte elements");
+  if (!src || !dst) return fail(kErrInvalidArgument, "seld_gru_to_tile: null pointer");
+  const long tiles = (B + kSeqs - 1) / kSeqs;
+  const dim3 grid(static_cast<unsigned>(tiles * T * 2));
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (elem_bytes == 2) hipLaunchKernelGGL(gru_to_tile_kernel<uint2>, grid, dim3(256), 0, stream,
+                                          static_cast<const uint2*>(src), static_cast<long>(B), static_cast<long>(T), ns,
+                                          static_cast<uint2*>(dst));
+  else hipLaunchKernelGGL(gru_to_tile_kernel<float4>, grid, dim3(256), 0, stream, static_cast<const float4*>(src),
+                          static_cast<long>(B), static_cast<long>(T), ns, static_cast<float4*>(dst));
+  SELD_HIP_TRY(hipGetLastError());
+  return kOk;
+}
+
+int seld_gru_from_pair_tile(const void* dg_tile, int elem_bytes, int64_t B, int64_t T, void* dgi, void* dghn,
+                            void* stream_) {
+  using namespace seld;
+  if (!current_state()) return kErrNotInitialised;
+  if (B <= 0 || T <= 0) return fail(kErrInvalidArgument, "seld_gru_from_pair_tile: B and T must be positive");
+  if (elem_bytes != 2 && elem_bytes != 4) return fail(kErrUnsupported, "seld_gru_from_pair_tile: 2- or 4-byte elements");
+  if (!dg_tile || !dgi || !dghn) return fail(kErrInvalidArgument, "seld_gru_from_pair_tile: null pointer");
+  const long tiles = (B + kSeqs - 1) / kSeqs;
+  const dim3 grid(static_cast<unsigned>(tiles * T * 2));
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (elem_bytes == 2) hipLaunchKernelGGL(gru_from_pair_tile_kernel<uint2>, grid, dim3(256), 0, stream,
+                                          static_cast<const Pair<uint2>*>(dg_tile), static_cast<long>(B),
+                                          static_cast<long>(T), static_cast<uint2*>(dgi), static_cast<uint2*>(dghn));
+  else hipLaunchKernelGGL(gru_from_pair_tile_kernel<float4>, grid, dim3(256), 0, stream,
+                          static_cast<const Pair<float4>*>(dg_tile), static_cast<long>(B), static_cast<long>(T),
+                          static_cast<float4*>(dgi), static_cast<float4*>(dghn));
+  SELD_HIP_TRY(hipGetLastError());
+  return kOk;
+}
 
 int64_t seld_gru_tile_rows(void) { return seld::kSeqs; }
 

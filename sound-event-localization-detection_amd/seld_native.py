@@ -67,6 +67,8 @@ def _declare(lib):
     lib.seld_conv_tail_forward.argtypes = [_ptr, _int, _i64, _int, _int, _ptr, _ptr, _ptr, _ptr, ctypes.c_float,
                                            ctypes.c_float, _int, _ptr, _ptr, _ptr, _ptr, _ptr]
     lib.seld_conv_tail_backward.argtypes = [_ptr, _ptr, _int, _i64, _int, _int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]
+    lib.seld_gru_to_tile.argtypes = [_ptr, _int, _i64, _i64, _int, _ptr, _ptr]
+    lib.seld_gru_from_pair_tile.argtypes = [_ptr, _int, _i64, _i64, _ptr, _ptr, _ptr]
     lib.seld_gru_tile_rows.restype = _i64
     lib.seld_gru_tile_rows.argtypes = []
     lib.seld_gru_forward.argtypes = [_ptr, _int, _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr]
@@ -415,6 +417,29 @@ def from_pair_tile(x: torch.Tensor, batch: int):
     return (dgi.view(tiles * GRU_TILE, t, 2, 3, GRU_H)[:batch], dghn.view(tiles * GRU_TILE, t, 2, GRU_H)[:batch])
 
 
+def to_tile_device(x: torch.Tensor, ns: int) -> torch.Tensor:
+    """``to_tile`` by the HIP permute kernel (x: contiguous GPU tensor [B, T, 2, ns, 256], bf16 or fp32)."""
+    b, t = x.shape[0], x.shape[1]
+    tiles = (b + GRU_TILE - 1) // GRU_TILE
+    x = x.contiguous()
+    out = torch.empty((tiles, t, 2, 8, ns, 4, 2, GRU_TILE, 4), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(ensure_init(x.device)):
+        check(load_library().seld_gru_to_tile(_p(x), x.element_size(), b, t, ns, _p(out), _stream_ptr(x.device)),
+              "seld_gru_to_tile")
+    return out
+
+
+def from_pair_tile_device(x: torch.Tensor, batch: int):
+    """``from_pair_tile`` by the HIP permute kernel."""
+    t = x.shape[1]
+    dgi = torch.empty((batch, t, 2, 3, GRU_H), dtype=x.dtype, device=x.device)
+    dghn = torch.empty((batch, t, 2, GRU_H), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(ensure_init(x.device)):
+        check(load_library().seld_gru_from_pair_tile(_p(x), x.element_size(), batch, t, _p(dgi), _p(dghn),
+                                                     _stream_ptr(x.device)), "seld_gru_from_pair_tile")
+    return dgi, dghn
+
+
 def gru_forward(gi: torch.Tensor, w_hh: torch.Tensor, b_hn: torch.Tensor, need_saved: bool):
     """gi [B, T, 2, 3H] (fp32 / bf16; must already include b_ih and the r/z part of b_hh), w_hh [2, 3H, H],
     b_hn [2, H] (n-gate recurrent bias) -> (y [B, T, 2H], saved (tile layout, opaque) or None).  y is a view of
@@ -426,7 +451,7 @@ def gru_forward(gi: torch.Tensor, w_hh: torch.Tensor, b_hn: torch.Tensor, need_s
     if two != 2 or h != GRU_H or gi.dtype not in (torch.float32, torch.bfloat16):
         raise ValueError("gru_forward: gi must be [B, T, 2, 768] float32 or bfloat16")
     index = ensure_init(gi.device)
-    gi_tile = to_tile(gi.reshape(b, t, 2, 3, h), 3)
+    gi_tile = to_tile_device(gi.reshape(b, t, 2, 3, h), 3)
     tiles = gi_tile.shape[0]
     w = w_hh.to(torch.bfloat16).contiguous()
     bias = b_hn.to(torch.float32).contiguous()
@@ -452,7 +477,7 @@ def gru_backward(dy: torch.Tensor, saved: torch.Tensor, y: torch.Tensor, w_hh: t
         raise ValueError("gru_backward: saved activations do not belong to a forward pass of this dtype")
     if y.dtype != dy.dtype or tuple(y.shape) != (b, t, h2):
         raise ValueError("gru_backward: y must be the forward output matching dy")
-    dy_tile = to_tile(dy.reshape(b, t, 2, 1, h), 1)
+    dy_tile = to_tile_device(dy.reshape(b, t, 2, 1, h), 1)
     tiles = dy_tile.shape[0]
     if tiles * GRU_TILE != b:               # the kernel reads whole tiles of y (h_{t-1}); pad rows are never used
         y = torch.cat((y, y.new_zeros((tiles * GRU_TILE - b, t, h2))), dim=0)
@@ -464,7 +489,7 @@ def gru_backward(dy: torch.Tensor, saved: torch.Tensor, y: torch.Tensor, w_hh: t
         check(load_library().seld_gru_backward(_p(dy_tile), _p(saved), _p(y), int(dy.dtype == torch.bfloat16),
                                                _p(w_t), tiles, t, h, _p(dg_tile), _p(dbias), _stream_ptr(dy.device)),
               "seld_gru_backward")
-    dgi, dghn = from_pair_tile(dg_tile, b)
+    dgi, dghn = from_pair_tile_device(dg_tile, b)
     return dgi, dghn, dbias.sum(dim=0) if tiles > 1 else dbias[0]
 
 

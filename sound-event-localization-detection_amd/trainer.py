@@ -86,7 +86,11 @@ def prepare_model_for_device(model, device):
     SeldGRU.fused_enabled = bool(getattr(config, "FUSED_GRU", True))
     if device.type == "cuda":
         import seld_convtail
+        import seld_gru
         seld_convtail.enabled = bool(getattr(config, "FUSED_CONV_TAIL", True))
+        for module in model.modules():
+            if isinstance(module, SeldGRU) and SeldGRU.fused_enabled:
+                seld_gru.pack_parameters(module)
     SMRSELDLoss.fused_enabled = bool(getattr(config, "FUSED_LOSS", True))
     return model
 

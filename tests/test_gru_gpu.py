@@ -88,3 +88,18 @@ def test_two_layer_bf16_autocast_tracks_nn_gru(gpu_device):
     assert got.dtype == torch.bfloat16
     assert (got.float() - ref).abs().max().item() <= 5e-2
     assert (got_h.float() - ref_h).abs().max().item() <= 5e-2
+
+
+@pytest.mark.parametrize("batch,steps,ns,dtype", [(32, 250, 3, torch.bfloat16), (5, 7, 1, torch.bfloat16), (11, 3, 3, torch.float32)])
+def test_layout_converters_match_the_torch_permutes(gpu_device, batch, steps, ns, dtype):
+    """seld_gru_to_tile / seld_gru_from_pair_tile (index work, bit-exact) against the torch permutes that define
+    the tile layout (seld_native.to_tile / from_pair_tile)."""
+    import seld_native
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(batch, steps, 2, ns, H, generator=g).to(dtype).to(gpu_device)
+    assert torch.equal(seld_native.to_tile_device(x, ns), seld_native.to_tile(x, ns))
+    tiles = (batch + 7) // 8
+    dg = torch.randn(tiles, steps, 2, 8, 2, 4, 2, 8, 2, 4, generator=g).to(dtype).to(gpu_device)
+    dgi, dghn = seld_native.from_pair_tile_device(dg, batch)
+    ref_gi, ref_n = seld_native.from_pair_tile(dg, batch)
+    assert torch.equal(dgi, ref_gi) and torch.equal(dghn, ref_n)
