@@ -163,6 +163,71 @@ def measured_traffic_per_clip():
     return best
 
 
+def kernel_rooflines(device):
+    """Every other hand-written kernel of the path against the roofline that bounds it, at the workload's shapes
+    (batch 32 windows), timed with HIP events on the launch stream AFTER the timed region (not part of `value`).
+    HBM kernels: algorithmic bytes per launch / duration vs the 8 TB/s peak.  The GRU recurrence runs on 8 CUs
+    (one per direction and 8-sequence tile): its 2*B*T*2*H*3H flop against those CUs' dense bf16 MFMA peak."""
+    import seld_native as nat
+    out = []
+
+    def timeit(fn, reps=10):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    def hbm(name, nbytes, seconds):
+        gbs = nbytes / seconds / 1e9
+        out.append({"kernel": name, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbs / HBM_PEAK_GBS, "bytes_per_launch": nbytes, "avg_launch_ms": seconds * 1e3})
+
+    # conv-block tail (csrc/convtail.hip): 5 B (forward) / 8 B (backward) per pre-pool bf16 element
+    for c, f in ((64, 64), (512, 8)):
+        x = torch.randn(BATCH, c, WINDOW, f, device=device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w, b = torch.ones(c, device=device), torch.zeros(c, device=device)
+        rm, rv = torch.zeros(c, device=device), torch.ones(c, device=device)
+        y, mi, ss = nat.conv_tail_forward(x, w, b, rm, rv, 0.1, 1e-5, True, 2)
+        go = torch.randn_like(y)
+        hbm(f"seld::tail_stats+apply (BN+ReLU+MaxPool forward, C={c})", 5 * x.numel(),
+            timeit(lambda: nat.conv_tail_forward(x, w, b, rm, rv, 0.1, 1e-5, True, 2)))
+        hbm(f"seld::tail_bwd_reduce+apply (BN+ReLU+MaxPool backward, C={c})", 8 * x.numel(),
+            timeit(lambda: nat.conv_tail_backward(x, go, mi, ss, 2)))
+    # fused softmax-MSE value + gradient (csrc/loss.hip): bf16 logits read + gradient written + mask read
+    logits = torch.randn(BATCH, WINDOW, 648, 14, device=device).to(torch.bfloat16)
+    mask = torch.zeros(BATCH, WINDOW, 648, dtype=torch.uint16, device=device)
+    hbm("seld::softmax_mse_kernel (loss + gradient)", 2 * logits.numel() * 2 + mask.numel() * 2,
+        timeit(lambda: nat.softmax_mse(logits, mask, grad_scale=1.0)))
+    # label mask expansion and window gather (csrc/labels.hip)
+    starts = torch.arange(0, BATCH * HOP, HOP, dtype=torch.int64, device=device)
+    tm = torch.zeros(BATCH * HOP + WINDOW, 648, dtype=torch.uint16, device=device)
+    hbm("seld::gather_rows_kernel (label mask windows)", 2 * BATCH * WINDOW * 648 * 2,
+        timeit(lambda: nat.gather_windows(tm, starts, WINDOW)))
+    # GRU recurrence (csrc/gru.hip)
+    h = 256
+    gi = (torch.randn(BATCH, WINDOW, 2, 3 * h, device=device) * 0.5).to(torch.bfloat16)
+    w_hh = (torch.rand(2, 3 * h, h, device=device) * 2 - 1) / 16
+    b_hn = torch.zeros(2, h, device=device)
+    dy = torch.randn(BATCH, WINDOW, 2 * h, device=device).to(torch.bfloat16)
+    y, saved = nat.gru_forward(gi, w_hh, b_hn, True)
+    flop = 2.0 * BATCH * WINDOW * 2 * h * 3 * h
+    cus = 2 * ((BATCH + 7) // 8)
+    peak = MFMA_BF16_PEAK_TFLOPS * cus / 256.0
+    for name, fn in (("seld::gru_forward_kernel (+ layout permute)", lambda: nat.gru_forward(gi, w_hh, b_hn, True)),
+                     ("seld::gru_backward_kernel (+ layout permutes)", lambda: nat.gru_backward(dy, saved, y, w_hh))):
+        sec = timeit(fn)
+        out.append({"kernel": name, "bound": f"mfma on {cus} CUs (one per direction and 8-sequence tile)",
+                    "achieved": flop / sec / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flop / sec / 1e12 / peak,
+                    "us_per_step": sec * 1e6 / WINDOW, "avg_launch_ms": sec * 1e3})
+    return out
+
+
 def cpu_baseline():
     """Oracle path on the host cores, bounded sample (about 20-30 s): log-mel of 2 clips via the
     torch.stft restatement, reference-equivalent CRNN fwd+bwd+Adam at batch 2 (3 iterations after
@@ -276,6 +341,8 @@ def main():
                                "bound": "mfma", "achieved": model_tflops, "peak": MFMA_BF16_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": model_tflops / MFMA_BF16_PEAK_TFLOPS, "avg_ms": model_ms},
         }
+        if world == 1:
+            line["kernels"] = kernel_rooflines(device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -32,159 +32,215 @@
 
 #include "seld_common.h"
 
+#ifndef SELD_GRU_SEQS
+#define SELD_GRU_SEQS 8
+#endif
+
 namespace seld {
 
 constexpr int kH = 256;            // hidden size (config.py:45 CRNN_RNN_HIDDEN)
 constexpr int kG = 3 * kH;         // gate rows r | z | n
-constexpr int kRows = 16;          // MFMA N (columns); rows of the LDS exchange tiles
-constexpr int kSeqs = 8;           // sequences per workgroup (columns 0..7; 8..15 are padding)
+constexpr int kRows = 16;          // MFMA N (columns)
+constexpr int kSeqs = SELD_GRU_SEQS;   // sequences per workgroup = valid MFMA columns (the rest are padding)
+constexpr int kParts = kRows / kSeqs;  // lanes of a 16-lane row that share one sequence
+constexpr int kU = 8 / kParts;         // hidden units a lane post-processes (of the 2 x 4 its column computes)
 constexpr int kGruThreads = 512;   // 8 wavefronts
 constexpr int kHPitch = kH + 8;    // bf16 elements per h row in LDS (528 B)
 constexpr int kDghPitch = kG + 8;  // bf16 elements per dgh row in LDS (1552 B)
 constexpr int kWnBytes = 8 * 2 * 8 * 64 * 16;   // [wave][tile][kstep][lane] x 16 B = 131072
+static_assert(kSeqs == 8 || kSeqs == 4, "8 or 4 sequences per tile");
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-__device__ __forceinline__ float to_float(float v) { return v; }
-__device__ __forceinline__ float to_float(__hip_bfloat16 v) { return __bfloat162float(v); }
-template <typename T> __device__ __forceinline__ T from_float(float v);
-template <> __device__ __forceinline__ float from_float<float>(float v) { return v; }
-template <> __device__ __forceinline__ __hip_bfloat16 from_float<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
 
 // v_exp_f32 / v_rcp_f32 (1 ulp) instead of the IEEE division sequence: the gates are fp32 but not bit-critical
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // tanh(x) = 1 - 2 / (1 + e^{2x}): saturates correctly (e = inf -> 1, e = 0 -> -1) without a clamp
 __device__ __forceinline__ float tanh_f(float x) { return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)), 1.0f); }
 
-// Lanes 8..15 of every 16-lane row take `hi` from the lane 8 to their left (row_shr:8), lanes 0..7 keep `lo`.
-// bank_mask 0b1100 enables the write for banks 2, 3 (lanes 8..15 of the row) only.
-__device__ __forceinline__ float take_second_tile(float lo, float hi) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lo), __float_as_int(hi), 0x118, 0xf, 0xc, false));
+// ---- which values of its column's 2 x 4 accumulators a lane post-processes -------------------------------------
+// Column c of a 16-lane row holds sequence c % kSeqs; the kParts lanes that share a sequence split the 8 values
+// (unit tile s = 0, 1; unit i = 0..3; flat index 4 s + i) of the ONE valid column (part 0's) among themselves:
+// part p = c / kSeqs takes flat indices p kU .. p kU + kU - 1, fetched from the lane p kSeqs to its left with
+// one DPP row shift (row_shr) per value; bank_mask enables the write only for the lanes of that part.
+template <int kPart> __device__ __forceinline__ float shifted_part(float old, float src) {
+  constexpr int ctrl = 0x110 + kPart * kSeqs;                                       // row_shr:(kPart * kSeqs)
+  constexpr int banks = kSeqs == 8 ? 0xc : (1 << kPart);                            // banks = groups of 4 lanes
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), ctrl, 0xf, banks, false));
+}
+// v[s][i]: this column's accumulators; returns the kU values this lane owns
+__device__ __forceinline__ void own_values(const f32x4 (&v)[2], float (&out)[kU]) {
+#pragma unroll
+  for (int j = 0; j < kU; ++j) {
+    float r = v[j >> 2][j & 3];                                                      // part 0: flat index j
+    if (kParts >= 2) r = shifted_part<1>(r, v[(kU + j) >> 2][(kU + j) & 3]);
+    if (kParts == 4) {
+      r = shifted_part<2>(r, v[(2 * kU + j) >> 2][(2 * kU + j) & 3]);
+      r = shifted_part<3>(r, v[(3 * kU + j) >> 2][(3 * kU + j) & 3]);
+    }
+    out[j] = r;
+  }
 }
 
-// 4 consecutive hidden units of one sequence, as stored in global memory
-template <typename T> struct Vec4;
-template <> struct Vec4<float> { typedef float4 type; };
-template <> struct Vec4<__hip_bfloat16> { typedef uint2 type; };
+// ---- storage of a lane's kU-unit group ---------------------------------------------------------------------------
+template <int kBytes> struct Raw;
+template <> struct alignas(4) Raw<4> { unsigned w[1]; };
+template <> struct alignas(8) Raw<8> { unsigned w[2]; };
+template <> struct alignas(16) Raw<16> { unsigned w[4]; };
+template <> struct alignas(16) Raw<32> { unsigned w[8]; };
 
-__device__ __forceinline__ void unpack4(const float4& v, float (&f)[4]) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
-__device__ __forceinline__ void unpack4(const uint2& v, float (&f)[4]) {
-  f[0] = __uint_as_float(v.x << 16);
-  f[1] = __uint_as_float(v.x & 0xffff0000u);
-  f[2] = __uint_as_float(v.y << 16);
-  f[3] = __uint_as_float(v.y & 0xffff0000u);
-}
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return static_cast<unsigned>(__bfloat16_as_ushort(__float2bfloat16(lo))) |
          (static_cast<unsigned>(__bfloat16_as_ushort(__float2bfloat16(hi))) << 16);
 }
-__device__ __forceinline__ void pack4(const float (&f)[4], float4& v) { v = make_float4(f[0], f[1], f[2], f[3]); }
-__device__ __forceinline__ void pack4(const float (&f)[4], uint2& v) { v = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3])); }
-
-// Saved activations (r, z, n, gh_n, h) for the backward pass: fp32 in the fp32 build; fp16 in the bf16 build
-// (all five are O(1) values -- r, z in (0,1), n, h in (-1,1) -- so fp16's 11-bit significand keeps them 8x
-// finer than bf16 would, at half of fp32's bytes).
-template <typename T> struct SavedVec;
-template <> struct SavedVec<float> { typedef float4 type; };
-template <> struct SavedVec<__hip_bfloat16> { typedef uint2 type; };
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
   const f32x2 v = {lo, hi};
-  const f16x2 hv = __builtin_convertvector(v, f16x2);       // round to nearest even
-  return __builtin_bit_cast(unsigned, hv);
-}
-__device__ __forceinline__ void pack_saved(const float (&f)[4], float4& v) { v = make_float4(f[0], f[1], f[2], f[3]); }
-__device__ __forceinline__ void pack_saved(const float (&f)[4], uint2& v) {
-  v = make_uint2(pack_f16x2(f[0], f[1]), pack_f16x2(f[2], f[3]));
-}
-__device__ __forceinline__ void unpack_saved(const float4& v, float (&f)[4]) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
-__device__ __forceinline__ void unpack_saved(const uint2& v, float (&f)[4]) {
-  const f16x2 a = __builtin_bit_cast(f16x2, v.x), b = __builtin_bit_cast(f16x2, v.y);
-  f[0] = static_cast<float>(a[0]);
-  f[1] = static_cast<float>(a[1]);
-  f[2] = static_cast<float>(b[0]);
-  f[3] = static_cast<float>(b[1]);
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));            // round to nearest even
 }
 
-// Two 4-unit groups of one lane stored side by side (one 16-byte access in the bf16 build): the CU's store path is
-// ISSUE-bound (MI355X_MICROARCH.md, "store-ISSUE-bound ... 8x dwordx4 halves it"), so per step the saved
-// activations go out as 2 stores (r|z, n|gh_n) and the gate gradients as 2 (da_r|da_z, da_n|da_n*r).
-template <typename V> struct Pair { V a, b; };
-template <> struct alignas(16) Pair<uint2> { uint2 a, b; };
-template <> struct alignas(16) Pair<float4> { float4 a, b; };
+struct AsF32 {       // fp32 build: data and saved activations
+  static constexpr int kBytes = 4;
+  template <int N> static __device__ __forceinline__ void enc(const float (&f)[N], unsigned* w) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) w[k] = __float_as_uint(f[k]);
+  }
+  template <int N> static __device__ __forceinline__ void dec(const unsigned* w, float (&f)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) f[k] = __uint_as_float(w[k]);
+  }
+};
+struct AsBF16 {      // bf16 build: streamed data (gi, dy, dg, y)
+  static constexpr int kBytes = 2;
+  template <int N> static __device__ __forceinline__ void enc(const float (&f)[N], unsigned* w) {
+#pragma unroll
+    for (int k = 0; k < N / 2; ++k) w[k] = pack_bf16x2(f[2 * k], f[2 * k + 1]);
+  }
+  template <int N> static __device__ __forceinline__ void dec(const unsigned* w, float (&f)[N]) {
+#pragma unroll
+    for (int k = 0; k < N / 2; ++k) {
+      f[2 * k] = __uint_as_float(w[k] << 16);
+      f[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+    }
+  }
+};
+// Saved activations of the bf16 build: IEEE fp16.  r, z in (0,1), n in (-1,1), gh_n = O(1): fp16's 11-bit significand
+// keeps them 8x finer than bf16 would at half of fp32's bytes (bytes per step per CU are what bounds the recurrence).
+struct AsF16 {
+  static constexpr int kBytes = 2;
+  template <int N> static __device__ __forceinline__ void enc(const float (&f)[N], unsigned* w) {
+#pragma unroll
+    for (int k = 0; k < N / 2; ++k) w[k] = pack_f16x2(f[2 * k], f[2 * k + 1]);
+  }
+  template <int N> static __device__ __forceinline__ void dec(const unsigned* w, float (&f)[N]) {
+#pragma unroll
+    for (int k = 0; k < N / 2; ++k) {
+      const f16x2 h = __builtin_bit_cast(f16x2, w[k]);
+      f[2 * k] = static_cast<float>(h[0]);
+      f[2 * k + 1] = static_cast<float>(h[1]);
+    }
+  }
+};
+template <typename T> struct Types;
+template <> struct Types<float> { typedef AsF32 Data; typedef AsF32 Saved; };
+template <> struct Types<__hip_bfloat16> { typedef AsBF16 Data; typedef AsF16 Saved; };
+
+// one group / two groups side by side (one access): the CU's store path is ISSUE-bound (MI355X_MICROARCH.md,
+// "store-ISSUE-bound ... 8x dwordx4 halves it"), so per step the saved activations go out as 2 stores
+// (r|z, n|gh_n) and the gate gradients as 2 (da_r|da_z, da_n|da_n*r).
+template <typename C> using Group = Raw<C::kBytes * kU>;
+template <typename C> using PairOf = Raw<2 * C::kBytes * kU>;
+template <typename C> __device__ __forceinline__ Group<C> enc1(const float (&a)[kU]) {
+  Group<C> g;
+  C::template enc<kU>(a, g.w);
+  return g;
+}
+template <typename C> __device__ __forceinline__ void dec1(const Group<C>& g, float (&a)[kU]) { C::template dec<kU>(g.w, a); }
+template <typename C> __device__ __forceinline__ PairOf<C> enc2(const float (&a)[kU], const float (&b)[kU]) {
+  PairOf<C> p;
+  C::template enc<kU>(a, p.w);
+  C::template enc<kU>(b, p.w + C::kBytes * kU / 4);
+  return p;
+}
+template <typename C> __device__ __forceinline__ void dec2(const PairOf<C>& p, float (&a)[kU], float (&b)[kU]) {
+  C::template dec<kU>(p.w, a);
+  C::template dec<kU>(p.w + C::kBytes * kU / 4, b);
+}
 
 // ---- private "tile" layout of every per-step tensor the kernels stream (gi, saved gates, dy, dg) --------
-// Lane (q = lane>>4, c = lane&15) of wavefront w owns sequence (c & 7) of its 8-sequence tile and the 4 units
-// 32w + 16(c>>3) + 4q .. +3.  Storing the 4-unit group of lane `lane` at
+// Lane (q = lane>>4, c = lane&15) of wavefront w owns sequence c % kSeqs of its tile and the kU units starting at
+//     unit0 = 32w + 4q + [flat index p kU decomposed as 16 s + i],   p = c / kSeqs.
+// Storing the group of lane `lane` at
 //     group(tile, t, dir, w, slot, lane) = (((((tile*T + t)*2 + dir)*8 + w)*NS + slot)*64 + lane)
-// (x4 elements) makes every load / store instruction of a wavefront ONE contiguous 512 B / 1 KB run.
-// In the natural [B][T][...][H] layout the same instruction touches 8 rows x 32..64 B: measured, the
-// CU's store path then takes ~1.6 us per step for the stores of a step -- more than all the arithmetic.
-// The host converts gi / dy into this layout and dg back with one permute each (tens of MB, microseconds).
+// makes every load / store instruction of a wavefront ONE contiguous run.  In the natural [B][T][...][H] layout
+// the same instruction touches kSeqs rows x 16..64 B: measured, the CU's store path then takes ~1.6 us per step
+// for the stores of a step -- more than all the arithmetic.  seld_gru_to_tile / seld_gru_from_pair_tile convert.
 __device__ __forceinline__ long tile_group(long tile, long T, long t, int dir, int w, int ns, int slot, int lane) {
   return (((((tile * T + t) * 2 + dir) * 8 + w) * ns + slot) * 64 + lane);
+}
+__device__ __forceinline__ int lane_unit0(int wave, int lane) {
+  const int q = lane >> 4, part = (lane & 15) / kSeqs;
+  const int flat = part * kU;                          // 4 s + i
+  return 32 * wave + 16 * (flat >> 2) + 4 * q + (flat & 3);
 }
 
 struct GruFwdArgs {
   const void* gi;        // tile layout, NS = 3 (r | z | n), dtype T; r/z already include b_hh
   const __hip_bfloat16* w_hh;   // [2][3H][H]
   const float* b_hn;     // [2][H]    recurrent bias of the n gate
-  void* y;               // [tiles*8][T][2H]  natural layout (what the next layer's GEMM reads), dtype T
-  void* saved;           // tile layout, NS = 2 pairs (r|z, n|gh_n) of SavedVec<T> groups (nullptr: inference)
+  void* y;               // [tiles*kSeqs][T][2H]  natural layout (what the next layer's GEMM reads), dtype T
+  void* saved;           // tile layout, NS = 2 pairs (r|z, n|gh_n), Saved encoding (nullptr: inference)
   long tiles, T;
 };
 
-// The MFMA computes gh^T = W_hh h^T: M = gate rows (units), N = sequence columns; with D[m = 4q+i][n = c] a lane
-// holds 4 consecutive units of one column.  The step body has NO divergent control flow (batch padded to whole
-// tiles by the host; kSave compile time): the compiler counts outstanding loads / stores exactly and never
-// drains the queue.
+// The MFMA computes gh^T = W_hh h^T: M = gate rows (units), N = sequence columns; D[m = 4q+i][n = c].  The step
+// body has NO divergent control flow (batch padded to whole tiles by the host; kSave compile time): the compiler
+// counts outstanding loads / stores exactly and never drains the queue.
 template <typename T, bool kSave>
 __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* wn_lds, __hip_bfloat16* hbuf,
                                                   const bf16x8 (&wr)[2][8], const bf16x8 (&wz)[2][8]) {
-  typedef typename Vec4<T>::type V4;
-  typedef typename SavedVec<T>::type SV;
+  typedef typename Types<T>::Data D;
+  typedef typename Types<T>::Saved S;
   constexpr bool kLdsY = sizeof(T) == 2;   // bf16: y rows are written from the LDS h tile (512-B runs)
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int q = lane >> 4, c = lane & 15;
-  const int seq = c & 7, s_own = c >> 3;
-  const int unit0 = 32 * wave + 16 * s_own + 4 * q;       // the 4 units this lane post-processes
+  const int seq = c % kSeqs;
+  const int unit0 = lane_unit0(wave, lane);               // the kU units this lane post-processes
   const int dir = blockIdx.y;
   const long tile = blockIdx.x;
   const float* bh = a.b_hn + dir * kH;
-  const V4* gi = static_cast<const V4*>(a.gi);
+  const Group<D>* gi = static_cast<const Group<D>*>(a.gi);
   T* y = static_cast<T*>(a.y);
-  typedef Pair<SV> SP;
-  SP* saved = static_cast<SP*>(a.saved);
+  PairOf<S>* saved = static_cast<PairOf<S>*>(a.saved);
   const long b = tile * kSeqs + seq;       // this lane's sequence (natural-layout row)
 
-  float bias_n[4], h_prev[4];
+  float bias_n[kU], h_prev[kU];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < kU; ++i) {
     bias_n[i] = bh[unit0 + i];
     h_prev[i] = 0.0f;
   }
 
   auto time_of = [&](long step) { return dir == 0 ? step : a.T - 1 - step; };
-  auto load_gi = [&](long step, V4 (&g)[3]) {
+  auto load_gi = [&](long step, Group<D> (&g)[3]) {
     // one base pointer per step + compile-time offsets (gate*64 groups): a single address register
-    const V4* p = gi + tile_group(tile, a.T, time_of(step), dir, wave, 3, 0, lane);
+    const Group<D>* p = gi + tile_group(tile, a.T, time_of(step), dir, wave, 3, 0, lane);
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate) g[gate] = p[gate * 64];
   };
 
   // `g` holds this step's operands on entry; they are unpacked at once and the SAME registers then receive
   // the next step's operands (a whole step of cover), so no second operand set is needed.
-  auto step = [&](long t, V4 (&g)[3]) {
+  auto step = [&](long t, Group<D> (&g)[3]) {
     const long tt = time_of(t);
     const int cur = static_cast<int>(t & 1), nxt = cur ^ 1;
-    SP* const save_base = kSave ? saved + tile_group(tile, a.T, tt, dir, wave, 2, 0, lane) : nullptr;
-    float gir[4], giz[4], gin[4];
-    unpack4(g[0], gir);                    // gi already holds b_ih + b_hh for the r and z gates
-    unpack4(g[1], giz);
-    unpack4(g[2], gin);
+    PairOf<S>* const save_base = kSave ? saved + tile_group(tile, a.T, tt, dir, wave, 2, 0, lane) : nullptr;
+    float gir[kU], giz[kU], gin[kU];
+    dec1<D>(g[0], gir);                    // gi already holds b_ih + b_hh for the r and z gates
+    dec1<D>(g[1], giz);
+    dec1<D>(g[2], gin);
     // operands of the next step: unconditional (clamped at the last step) and pinned here -- the scheduler
     // otherwise sinks the loads below this step's stores, and the in-order vmcnt then makes the next step
     // wait for those stores' round trip.
@@ -192,13 +248,14 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
     load_gi(t + 1 < a.T ? t + 1 : a.T - 1, g);
     __builtin_amdgcn_sched_barrier(0);
     // ---- gh^T = W_hh h^T : B fragments (k, n = column c) of h_{t-1} and the n-gate A fragments from LDS,
-    // read one k-step ahead of the MFMAs that consume them (the LDS latency hides under 6 MFMAs)
+    // read one k-step ahead of the MFMAs that consume them (the LDS latency hides under 6 MFMAs).  The padding
+    // columns read row c % kSeqs again: their results are never used.
     f32x4 acc_r[2], acc_z[2], acc_n[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc_r[s][i] = acc_z[s][i] = acc_n[s][i] = 0.0f;
-    const __hip_bfloat16* hrow = hbuf + (cur * kRows + c) * kHPitch + 8 * q;
+    const __hip_bfloat16* hrow = hbuf + (cur * kSeqs + seq) * kHPitch + 8 * q;
     const bf16x8* wnp = wn_lds + wave * 2 * 8 * 64 + lane;
     bf16x8 hfrag = *reinterpret_cast<const bf16x8*>(hrow);
     bf16x8 wn0 = wnp[0], wn1 = wnp[8 * 64];
@@ -220,46 +277,39 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
       wn0 = wn0_n;
       wn1 = wn1_n;
     }
-    // ---- gates for this lane's (sequence, 4 units): columns 0..7 keep unit tile 0, columns 8..15 take unit
-    // tile 1 of the column 8 to their left
-    float rr[4], zz[4], nn[4], gg[4], hh[4];
+    // ---- gates for this lane's (sequence, kU units)
+    float ghr[kU], ghz[kU], gg[kU], rr[kU], zz[kU], nn[kU], hh[kU];
+    own_values(acc_r, ghr);
+    own_values(acc_z, ghz);
+    own_values(acc_n, gg);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float ghr = take_second_tile(acc_r[0][i], acc_r[1][i]);
-      const float ghz = take_second_tile(acc_z[0][i], acc_z[1][i]);
-      gg[i] = take_second_tile(acc_n[0][i], acc_n[1][i]) + bias_n[i];
-      rr[i] = sigmoid_f(gir[i] + ghr);
-      zz[i] = sigmoid_f(giz[i] + ghz);
+    for (int i = 0; i < kU; ++i) {
+      gg[i] += bias_n[i];
+      rr[i] = sigmoid_f(gir[i] + ghr[i]);
+      zz[i] = sigmoid_f(giz[i] + ghz[i]);
       nn[i] = tanh_f(fmaf(rr[i], gg[i], gin[i]));
       hh[i] = fmaf(zz[i], h_prev[i] - nn[i], nn[i]);
       h_prev[i] = hh[i];
     }
-    uint2 hb;
-    pack4(hh, hb);
-    *reinterpret_cast<uint2*>(hbuf + (nxt * kRows + seq) * kHPitch + unit0) = hb;
-    if (!kLdsY) {
-      V4 yv;
-      pack4(hh, yv);
-      *reinterpret_cast<V4*>(y + (b * a.T + tt) * (2 * kH) + dir * kH + unit0) = yv;
-    }
-    if (kSave) {
-      SP v;                                // h itself is not saved: the backward pass reads h_{t-1} from y
-      pack_saved(rr, v.a);
-      pack_saved(zz, v.b);
-      save_base[0] = v;
-      pack_saved(nn, v.a);
-      pack_saved(gg, v.b);
-      save_base[64] = v;
+    *reinterpret_cast<Group<AsBF16>*>(hbuf + (nxt * kSeqs + seq) * kHPitch + unit0) = enc1<AsBF16>(hh);
+    if (!kLdsY) *reinterpret_cast<Group<D>*>(y + (b * a.T + tt) * (2 * kH) + dir * kH + unit0) = enc1<D>(hh);
+    if (kSave) {                           // h itself is not saved: the backward pass reads h_{t-1} from y
+      save_base[0] = enc2<S>(rr, zz);
+      save_base[64] = enc2<S>(nn, gg);
     }
     __syncthreads();
     if (kLdsY) {
-      // y[b][tt][dir*H .. +H) is a 512-B run: wavefront w writes row w of the fresh h tile
-      const uint2 v = *reinterpret_cast<const uint2*>(hbuf + (nxt * kRows + wave) * kHPitch + lane * 4);
-      *reinterpret_cast<uint2*>(y + ((tile * kSeqs + wave) * a.T + tt) * (2 * kH) + dir * kH + lane * 4) = v;
+      // y[b][tt][dir*H .. +H) is a 512-B run: the 8 wavefronts write the kSeqs rows of the fresh h tile, one row
+      // (kSeqs = 8) or half a row (kSeqs = 4) each, as one contiguous run per wavefront
+      constexpr int kPer = 4 * kSeqs / 8;                    // bf16 elements per lane
+      const int row = wave * kSeqs / 8, col = (wave % (8 / kSeqs)) * (64 * kPer) + lane * kPer;
+      typedef Raw<2 * kPer> Piece;
+      const Piece v = *reinterpret_cast<const Piece*>(hbuf + (nxt * kSeqs + row) * kHPitch + col);
+      *reinterpret_cast<Piece*>(y + ((tile * kSeqs + row) * a.T + tt) * (2 * kH) + dir * kH + col) = v;
     }
   };
 
-  V4 g[3];
+  Group<D> g[3];
   load_gi(0, g);
   // The first step is peeled so that the loop is ENTERED in the same memory-queue state as the back edge
   // leaves it; otherwise the compiler merges the two states conservatively and every step waits for the
@@ -273,7 +323,7 @@ template <typename T>
 __global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16x8* wn_lds = reinterpret_cast<bf16x8*>(smem);
-  __hip_bfloat16* hbuf = reinterpret_cast<__hip_bfloat16*>(smem + kWnBytes);   // [2][16][kHPitch]
+  __hip_bfloat16* hbuf = reinterpret_cast<__hip_bfloat16*>(smem + kWnBytes);   // [2][kSeqs][kHPitch]
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int q = lane >> 4, c = lane & 15;
@@ -296,8 +346,7 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs 
 #ifdef SELD_GRU_SKEW
   if (wave < 4) __builtin_amdgcn_s_setprio(SELD_GRU_SKEW);   // experiment: de-phase the two waves of a SIMD
 #endif
-  // rows 8..15 of both h tiles are never written again: the padding columns of every MFMA stay zero
-  for (int i = tid; i < 2 * kRows * kHPitch; i += kGruThreads) hbuf[i] = __float2bfloat16(0.0f);
+  for (int i = tid; i < 2 * kSeqs * kHPitch; i += kGruThreads) hbuf[i] = __float2bfloat16(0.0f);   // h_0 = 0
   __syncthreads();
   if (a.saved) gru_forward_steps<T, true>(a, wn_lds, hbuf, wr, wz);
   else gru_forward_steps<T, false>(a, wn_lds, hbuf, wr, wz);
@@ -305,8 +354,8 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs 
 
 struct GruBwdArgs {
   const void* dy;        // tile layout, NS = 1, dtype T
-  const void* saved;     // tile layout, NS = 2 pairs (r|z, n|gh_n) of SavedVec<T> groups
-  const void* y;         // [tiles*8][T][2H] the forward output (h_t), natural layout, dtype T
+  const void* saved;     // tile layout, NS = 2 pairs (r|z, n|gh_n), Saved encoding
+  const void* y;         // [tiles*kSeqs][T][2H] the forward output (h_t), natural layout, dtype T
   const __hip_bfloat16* w_hh_t;   // [2][H][3H]   W_hh transposed per direction
   void* dg;              // tile layout, NS = 2 pairs (da_r|da_z, da_n|da_n*r), dtype T
   float* dbias;          // [tiles][2][4][H]  per-tile sums over (sequence, t) of the four dg slots (fp32)
@@ -314,34 +363,32 @@ struct GruBwdArgs {
 };
 
 template <typename T> struct GruStepIn {
-  Pair<typename SavedVec<T>::type> rz, ng;
-  typename Vec4<T>::type hp, d;
+  PairOf<typename Types<T>::Saved> rz, ng;
+  Group<typename Types<T>::Data> hp, d;
 };
 
 // dh_prev^T = W_hh^T dgh^T : M = hidden units, N = sequence columns; same lane ownership as the forward kernel.
 template <typename T>
 __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* wn_lds, __hip_bfloat16* dgh,
                                                    const bf16x8 (&wrz)[2][16]) {
-  typedef typename Vec4<T>::type V4;
-  typedef typename SavedVec<T>::type SV;
+  typedef typename Types<T>::Data D;
+  typedef typename Types<T>::Saved S;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int q = lane >> 4, c = lane & 15;
-  const int seq = c & 7, s_own = c >> 3;
-  const int unit0 = 32 * wave + 16 * s_own + 4 * q;
+  const int seq = c % kSeqs;
+  const int unit0 = lane_unit0(wave, lane);
   const int dir = blockIdx.y;
   const long tile = blockIdx.x;
-  const V4* dy = static_cast<const V4*>(a.dy);
-  typedef Pair<SV> SP;
-  typedef Pair<V4> DP;
-  const SP* saved = static_cast<const SP*>(a.saved);
+  const Group<D>* dy = static_cast<const Group<D>*>(a.dy);
+  const PairOf<S>* saved = static_cast<const PairOf<S>*>(a.saved);
   const T* y = static_cast<const T*>(a.y);
-  DP* dg = static_cast<DP*>(a.dg);
+  PairOf<D>* dg = static_cast<PairOf<D>*>(a.dg);
   const long b = tile * kSeqs + seq;
 
-  float dh[4], bsum[4][4];           // bsum: running sums of da_r, da_z, da_n, da_n*r (the bias gradients)
+  float dh[kU], bsum[4][kU];         // bsum: running sums of da_r, da_z, da_n, da_n*r (the bias gradients)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < kU; ++i) {
     dh[i] = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) bsum[k][i] = 0.0f;
@@ -351,10 +398,10 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
   auto load_step = [&](long step, GruStepIn<T>& in) {
     const long tt = time_of(step);
     const long tprev = time_of(step > 0 ? step - 1 : 0);      // h_{t-1} of the forward recurrence (unused at step 0)
-    const SP* sp = saved + tile_group(tile, a.T, tt, dir, wave, 2, 0, lane);
+    const PairOf<S>* sp = saved + tile_group(tile, a.T, tt, dir, wave, 2, 0, lane);
     in.rz = sp[0];
     in.ng = sp[64];
-    in.hp = *reinterpret_cast<const V4*>(y + (b * a.T + tprev) * (2 * kH) + dir * kH + unit0);
+    in.hp = *reinterpret_cast<const Group<D>*>(y + (b * a.T + tprev) * (2 * kH) + dir * kH + unit0);
     in.d = dy[tile_group(tile, a.T, tt, dir, wave, 1, 0, lane)];
   };
 
@@ -362,19 +409,17 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
   // the operands of the next (earlier-in-time) step.
   auto step = [&](long t, GruStepIn<T>& in) {
     const long tt = time_of(t);
-    float r[4], z[4], n[4], g[4], hp[4], d[4];
-    unpack_saved(in.rz.a, r);
-    unpack_saved(in.rz.b, z);
-    unpack_saved(in.ng.a, n);
-    unpack_saved(in.ng.b, g);
-    unpack4(in.hp, hp);
-    unpack4(in.d, d);
+    float r[kU], z[kU], n[kU], g[kU], hp[kU], d[kU];
+    dec2<S>(in.rz, r, z);
+    dec2<S>(in.ng, n, g);
+    dec1<D>(in.hp, hp);
+    dec1<D>(in.d, d);
     __builtin_amdgcn_sched_barrier(0);
     load_step(t > 0 ? t - 1 : 0, in);              // unconditional, clamped; pinned ahead of this step's stores
     __builtin_amdgcn_sched_barrier(0);
-    float keep[4], da_r[4], da_z[4], da_n[4], dghn[4];
+    float keep[kU], da_r[kU], da_z[kU], da_n[kU], dghn[kU];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < kU; ++i) {
       const float hprev = t > 0 ? hp[i] : 0.0f;
       const float dtot = d[i] + dh[i];
       const float dn = dtot * (1.0f - z[i]);
@@ -389,22 +434,17 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
       bsum[2][i] += da_n[i];
       bsum[3][i] += dghn[i];
     }
-    DP* const gp = dg + tile_group(tile, a.T, tt, dir, wave, 2, 0, lane);
-    DP v;
-    pack4(da_r, v.a);
-    pack4(da_z, v.b);
-    gp[0] = v;
-    pack4(da_n, v.a);
-    pack4(dghn, v.b);
-    gp[64] = v;
-    __hip_bfloat16* drow = dgh + seq * kDghPitch + unit0;
-    uint2 pk;
-    pack4(da_r, pk);
-    *reinterpret_cast<uint2*>(drow) = pk;
-    pack4(da_z, pk);
-    *reinterpret_cast<uint2*>(drow + kH) = pk;
-    pack4(dghn, pk);
-    *reinterpret_cast<uint2*>(drow + 2 * kH) = pk;
+    PairOf<D>* const gp = dg + tile_group(tile, a.T, tt, dir, wave, 2, 0, lane);
+    gp[0] = enc2<D>(da_r, da_z);
+    gp[64] = enc2<D>(da_n, dghn);
+    // dgh tile: kSeqs rows, double buffered by step parity.  The padding columns of the MFMA read row c % kSeqs
+    // again (their results are never used), so no zero rows are needed, and with two buffers the step needs ONE
+    // barrier: a wavefront may start writing step t+1's tile while a slower one still reads step t's.
+    __hip_bfloat16* const dgh_cur = dgh + (t & 1) * (kSeqs * kDghPitch);
+    __hip_bfloat16* drow = dgh_cur + seq * kDghPitch + unit0;
+    *reinterpret_cast<Group<AsBF16>*>(drow) = enc1<AsBF16>(da_r);
+    *reinterpret_cast<Group<AsBF16>*>(drow + kH) = enc1<AsBF16>(da_z);
+    *reinterpret_cast<Group<AsBF16>*>(drow + 2 * kH) = enc1<AsBF16>(dghn);
     __syncthreads();
 
     // two independent accumulator chains per unit tile (even / odd k-steps): with a single chain per tile the
@@ -414,7 +454,7 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[s][0][i] = acc[s][1][i] = 0.0f;
-    const __hip_bfloat16* brow = dgh + c * kDghPitch + 8 * q;
+    const __hip_bfloat16* brow = dgh_cur + seq * kDghPitch + 8 * q;
     const bf16x8* wnp = wn_lds + wave * 2 * 8 * 64 + lane;
     // LDS fragments are read two k-steps ahead of the MFMAs that consume them
     bf16x8 d0 = *reinterpret_cast<const bf16x8*>(brow), d1 = *reinterpret_cast<const bf16x8*>(brow + 32);
@@ -433,10 +473,13 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
       d0 = d1;
       d1 = d2;
     }
+    f32x4 total[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      dh[i] = keep[i] + take_second_tile(acc[0][0][i] + acc[0][1][i], acc[1][0][i] + acc[1][1][i]);
-    __syncthreads();
+    for (int s = 0; s < 2; ++s) total[s] = acc[s][0] + acc[s][1];
+    float mine[kU];
+    own_values(total, mine);
+#pragma unroll
+    for (int i = 0; i < kU; ++i) dh[i] = keep[i] + mine[i];
   };
 
   GruStepIn<T> in;
@@ -446,22 +489,23 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
 #pragma unroll 1
   for (long t = a.T - 2; t >= 0; --t) step(t, in);
 
-  // bias gradients: add the 8 sequences of the tile (lanes that differ in c & 7), one float4 per slot and lane group
+  // bias gradients: add the kSeqs sequences of the tile (lanes that differ in c % kSeqs), one group per slot
 #pragma unroll
   for (int k = 0; k < 4; ++k)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < kU; ++i) {
       float v = bsum[k][i];
       v += __shfl_xor(v, 1);
       v += __shfl_xor(v, 2);
-      v += __shfl_xor(v, 4);
+      if (kSeqs == 8) v += __shfl_xor(v, 4);
       bsum[k][i] = v;
     }
   if (seq == 0) {
     float* out = a.dbias + ((tile * 2 + dir) * 4) * kH + unit0;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      *reinterpret_cast<float4*>(out + k * kH) = make_float4(bsum[k][0], bsum[k][1], bsum[k][2], bsum[k][3]);
+#pragma unroll
+      for (int i = 0; i < kU; ++i) out[k * kH + i] = bsum[k][i];
   }
 }
 
@@ -469,7 +513,7 @@ template <typename T>
 __global__ __launch_bounds__(kGruThreads, 2) void gru_backward_kernel(GruBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16x8* wn_lds = reinterpret_cast<bf16x8*>(smem);                               // k-range of the n gate
-  __hip_bfloat16* dgh = reinterpret_cast<__hip_bfloat16*>(smem + kWnBytes);       // [16][kDghPitch]
+  __hip_bfloat16* dgh = reinterpret_cast<__hip_bfloat16*>(smem + kWnBytes);       // [2][kSeqs][kDghPitch]
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int q = lane >> 4, c = lane & 15;
@@ -490,56 +534,68 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_backward_kernel(GruBwdArgs
 #ifdef SELD_GRU_SKEW
   if (wave < 4) __builtin_amdgcn_s_setprio(SELD_GRU_SKEW);
 #endif
-  // rows 8..15 (padding columns of the MFMA) stay zero for the whole kernel
-  for (int i = tid; i < kRows * kDghPitch; i += kGruThreads) dgh[i] = __float2bfloat16(0.0f);
   __syncthreads();
   gru_backward_steps<T>(a, wn_lds, dgh, wrz);
 }
 
 // ---- layout converters between the natural [B][T][2][NS][H] tensors of the host GEMMs and the tile layout ----
-// One block per (tile, t, direction): 8 sequences x NS x 64 four-unit groups.  The tile side is accessed as one
-// contiguous run per block; the natural side as 64-byte (bf16) / 128-byte (fp32) pieces of 512-B / 1-KB rows,
-// every byte exactly once.  HBM-bound permutes (read + write of the tensor), replacing strided framework copies.
-template <typename G>
-__global__ __launch_bounds__(256) void gru_to_tile_kernel(const G* __restrict__ src, long B, long T, int ns,
-                                                          G* __restrict__ dst) {
+// One block per (tile, t, direction): kSeqs sequences x NS x (256 / kU) groups.  The tile side is accessed as one
+// contiguous run per block; the natural side as short pieces of 512-B / 1-KB rows, every byte exactly once.
+// HBM-bound permutes (read + write of the tensor), replacing strided framework copies.
+__device__ __forceinline__ void lane_coords(int w, int lane, int& seq, int& ug) {
+  seq = (lane & 15) % kSeqs;
+  ug = lane_unit0(w, lane) / kU;                           // kU-unit group along H
+}
+
+template <int kGroupBytes>
+__global__ __launch_bounds__(256) void gru_to_tile_kernel(const Raw<kGroupBytes>* __restrict__ src, long B, long T,
+                                                          int ns, Raw<kGroupBytes>* __restrict__ dst) {
   const long blk = blockIdx.x;
   const int dir = static_cast<int>(blk & 1);
   const long t = (blk >> 1) % T, tile = (blk >> 1) / T;
   const int groups = 8 * ns * 64;
-  G zero;
-  __builtin_memset(&zero, 0, sizeof(G));
+  Raw<kGroupBytes> zero;
+  __builtin_memset(&zero, 0, sizeof(zero));
   for (int g = threadIdx.x; g < groups; g += 256) {
     const int lane = g & 63, slot = (g >> 6) % ns, w = (g >> 6) / ns;
-    const int seq = lane & 7, s = (lane >> 3) & 1, q = lane >> 4;
+    int seq, ug;
+    lane_coords(w, lane, seq, ug);
     const long b = tile * kSeqs + seq;
-    const int ug = 8 * w + 4 * s + q;                     // four-unit group along H: units 32w + 16s + 4q ..
-    G v = zero;
-    if (b < B) v = src[(((b * T + t) * 2 + dir) * ns + slot) * 64 + ug];
+    Raw<kGroupBytes> v = zero;
+    if (b < B) v = src[(((b * T + t) * 2 + dir) * ns + slot) * (kH / kU) + ug];
     dst[blk * groups + g] = v;
   }
 }
 
-template <typename G>
-__global__ __launch_bounds__(256) void gru_from_pair_tile_kernel(const Pair<G>* __restrict__ src, long B, long T,
-                                                                 G* __restrict__ dgi, G* __restrict__ dghn) {
+template <int kGroupBytes>
+__global__ __launch_bounds__(256) void gru_from_pair_tile_kernel(const Raw<2 * kGroupBytes>* __restrict__ src, long B,
+                                                                 long T, Raw<kGroupBytes>* __restrict__ dgi,
+                                                                 Raw<kGroupBytes>* __restrict__ dghn) {
   const long blk = blockIdx.x;
   const int dir = static_cast<int>(blk & 1);
   const long t = (blk >> 1) % T, tile = (blk >> 1) / T;
+  constexpr int kWords = kGroupBytes / 4;
+  constexpr int kRow = kH / kU;                            // groups per H
   for (int g = threadIdx.x; g < 8 * 2 * 64; g += 256) {
     const int lane = g & 63, ps = (g >> 6) & 1, w = g >> 7;
-    const int seq = lane & 7, s = (lane >> 3) & 1, q = lane >> 4;
+    int seq, ug;
+    lane_coords(w, lane, seq, ug);
     const long b = tile * kSeqs + seq;
     if (b >= B) continue;
-    const Pair<G> p = src[blk * (8 * 2 * 64) + g];
-    const int ug = 8 * w + 4 * s + q;
+    const Raw<2 * kGroupBytes> p = src[blk * (8 * 2 * 64) + g];
+    Raw<kGroupBytes> lo, hi;
+#pragma unroll
+    for (int k = 0; k < kWords; ++k) {
+      lo.w[k] = p.w[k];
+      hi.w[k] = p.w[kWords + k];
+    }
     const long row = (b * T + t) * 2 + dir;
     if (ps == 0) {
-      dgi[(row * 3 + 0) * 64 + ug] = p.a;                 // da_r
-      dgi[(row * 3 + 1) * 64 + ug] = p.b;                 // da_z
+      dgi[(row * 3 + 0) * kRow + ug] = lo;                 // da_r
+      dgi[(row * 3 + 1) * kRow + ug] = hi;                 // da_z
     } else {
-      dgi[(row * 3 + 2) * 64 + ug] = p.a;                 // da_n
-      dghn[row * 64 + ug] = p.b;                          // da_n * r
+      dgi[(row * 3 + 2) * kRow + ug] = lo;                 // da_n
+      dghn[row * kRow + ug] = hi;                          // da_n * r
     }
   }
 }
@@ -557,11 +613,11 @@ int seld_gru_to_tile(const void* src, int elem_bytes, int64_t B, int64_t T, int 
   const long tiles = (B + kSeqs - 1) / kSeqs;
   const dim3 grid(static_cast<unsigned>(tiles * T * 2));
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (elem_bytes == 2) hipLaunchKernelGGL(gru_to_tile_kernel<uint2>, grid, dim3(256), 0, stream,
-                                          static_cast<const uint2*>(src), static_cast<long>(B), static_cast<long>(T), ns,
-                                          static_cast<uint2*>(dst));
-  else hipLaunchKernelGGL(gru_to_tile_kernel<float4>, grid, dim3(256), 0, stream, static_cast<const float4*>(src),
-                          static_cast<long>(B), static_cast<long>(T), ns, static_cast<float4*>(dst));
+  if (elem_bytes == 2) hipLaunchKernelGGL(gru_to_tile_kernel<2 * kU>, grid, dim3(256), 0, stream,
+                                          static_cast<const Raw<2 * kU>*>(src), static_cast<long>(B),
+                                          static_cast<long>(T), ns, static_cast<Raw<2 * kU>*>(dst));
+  else hipLaunchKernelGGL(gru_to_tile_kernel<4 * kU>, grid, dim3(256), 0, stream, static_cast<const Raw<4 * kU>*>(src),
+                          static_cast<long>(B), static_cast<long>(T), ns, static_cast<Raw<4 * kU>*>(dst));
   SELD_HIP_TRY(hipGetLastError());
   return kOk;
 }
@@ -576,12 +632,13 @@ int seld_gru_from_pair_tile(const void* dg_tile, int elem_bytes, int64_t B, int6
   const long tiles = (B + kSeqs - 1) / kSeqs;
   const dim3 grid(static_cast<unsigned>(tiles * T * 2));
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (elem_bytes == 2) hipLaunchKernelGGL(gru_from_pair_tile_kernel<uint2>, grid, dim3(256), 0, stream,
-                                          static_cast<const Pair<uint2>*>(dg_tile), static_cast<long>(B),
-                                          static_cast<long>(T), static_cast<uint2*>(dgi), static_cast<uint2*>(dghn));
-  else hipLaunchKernelGGL(gru_from_pair_tile_kernel<float4>, grid, dim3(256), 0, stream,
-                          static_cast<const Pair<float4>*>(dg_tile), static_cast<long>(B), static_cast<long>(T),
-                          static_cast<float4*>(dgi), static_cast<float4*>(dghn));
+  if (elem_bytes == 2) hipLaunchKernelGGL(gru_from_pair_tile_kernel<2 * kU>, grid, dim3(256), 0, stream,
+                                          static_cast<const Raw<4 * kU>*>(dg_tile), static_cast<long>(B),
+                                          static_cast<long>(T), static_cast<Raw<2 * kU>*>(dgi),
+                                          static_cast<Raw<2 * kU>*>(dghn));
+  else hipLaunchKernelGGL(gru_from_pair_tile_kernel<4 * kU>, grid, dim3(256), 0, stream,
+                          static_cast<const Raw<8 * kU>*>(dg_tile), static_cast<long>(B), static_cast<long>(T),
+                          static_cast<Raw<4 * kU>*>(dgi), static_cast<Raw<4 * kU>*>(dghn));
   SELD_HIP_TRY(hipGetLastError());
   return kOk;
 }
@@ -598,7 +655,7 @@ int seld_gru_forward(const void* gi_tile, int is_bf16, const void* w_hh_bf16, co
   if (!gi_tile || !w_hh_bf16 || !b_hn || !y) return fail(kErrInvalidArgument, "seld_gru_forward: null pointer");
   GruFwdArgs a{gi_tile, static_cast<const __hip_bfloat16*>(w_hh_bf16), b_hn, y, saved_tile, tiles, T};
   const dim3 grid(static_cast<unsigned>(tiles), 2);
-  const size_t lds = kWnBytes + 2 * kRows * kHPitch * sizeof(__hip_bfloat16);
+  const size_t lds = kWnBytes + 2 * kSeqs * kHPitch * sizeof(__hip_bfloat16);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   static bool attr_done = false;          // not a stream operation: do it once so launches stay graph-capturable
   if (!attr_done) {
@@ -626,7 +683,7 @@ int seld_gru_backward(const void* dy_tile, const void* saved_tile, const void* y
     return fail(kErrInvalidArgument, "seld_gru_backward: null pointer");
   GruBwdArgs a{dy_tile, saved_tile, y, static_cast<const __hip_bfloat16*>(w_hh_t_bf16), dg_tile, dbias, tiles, T};
   const dim3 grid(static_cast<unsigned>(tiles), 2);
-  const size_t lds = kWnBytes + kRows * kDghPitch * sizeof(__hip_bfloat16);
+  const size_t lds = kWnBytes + 2 * kSeqs * kDghPitch * sizeof(__hip_bfloat16);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   static bool attr_done = false;
   if (!attr_done) {

@@ -15,7 +15,8 @@ from pathlib import Path
 import torch
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libseld_hip.so"
+# SELD_HIP_LIB: developer override to load an experimental build of the SAME library (A/B kernel experiments)
+LIB_PATH = Path(os.environ["SELD_HIP_LIB"]).resolve() if os.environ.get("SELD_HIP_LIB") else _HERE / "libseld_hip.so"
 
 N_FFT = 960
 HOP = 480
@@ -380,49 +381,61 @@ def conv_tail_backward(x, dy, mean_invstd, scale_shift, pool):
 
 # --------------------------------------------------------------------------- GRU recurrence
 
-GRU_TILE = 8          # sequences per workgroup (seld_gru_tile_rows(); the MFMA's other 8 columns are padding)
 GRU_H = 256
+GRU_TILE = 8          # sequences per workgroup; refreshed from seld_gru_tile_rows() when the library is loaded
+
+
+def _tile_geometry():
+    """(sequences per tile, lanes sharing a sequence, units per lane) of the loaded library (8, 2, 4) or (4, 4, 2)."""
+    global GRU_TILE
+    if LIB_PATH.exists():
+        GRU_TILE = int(load_library().seld_gru_tile_rows())
+    parts = 16 // GRU_TILE
+    return GRU_TILE, parts, 8 // parts
 
 
 def to_tile(x: torch.Tensor, ns: int) -> torch.Tensor:
-    """[B, T, 2, ns, 256] -> the kernels' tile layout [tiles, T, 2, 8(w), ns, 4(q), 2(s), 8(seq), 4(i)] (batch
-    zero-padded to whole 8-sequence tiles).  unit u = 32*w + 16*s + 4*q + i, row b = 8*tile + seq; the last three
-    lane dimensions (q, s, seq) are the wavefront lane q*16 + s*8 + seq."""
+    """[B, T, 2, ns, 256] -> the kernels' tile layout [tiles, T, 2, 8(w), ns, 4(q), parts, seqs, units] (batch
+    zero-padded to whole tiles); the torch definition of what seld_gru_to_tile does.  Hidden unit
+    u = 32*w + 16*s + 4*q + i with the flat index 4*s + i = part*units + j; row b = seqs*tile + seq; the lane
+    dimensions (q, part, seq) are the wavefront lane q*16 + part*seqs + seq."""
+    seqs, parts, units = _tile_geometry()
     b, t = x.shape[0], x.shape[1]
-    tiles = (b + GRU_TILE - 1) // GRU_TILE
-    if tiles * GRU_TILE != b:
-        x = torch.cat((x, x.new_zeros((tiles * GRU_TILE - b,) + tuple(x.shape[1:]))), dim=0)
-    x = x.reshape(tiles, GRU_TILE, t, 2, ns, 8, 2, 4, 4)             # tile, seq, T, dir, slot, w, s, q, i
-    return x.permute(0, 2, 3, 5, 4, 7, 6, 1, 8).contiguous()         # tile, T, dir, w, slot, q, s, seq, i
+    tiles = (b + seqs - 1) // seqs
+    if tiles * seqs != b:
+        x = torch.cat((x, x.new_zeros((tiles * seqs - b,) + tuple(x.shape[1:]))), dim=0)
+    x = x.reshape(tiles, seqs, t, 2, ns, 8, 2, 4, 4)                 # tile, seq, T, dir, slot, w, s, q, i
+    x = x.permute(0, 2, 3, 5, 4, 7, 6, 8, 1)                         # tile, T, dir, w, slot, q, s, i, seq
+    x = x.reshape(tiles, t, 2, 8, ns, 4, parts, units, seqs)         # (s, i) -> (part, j)
+    return x.permute(0, 1, 2, 3, 4, 5, 6, 8, 7).contiguous()         # tile, T, dir, w, slot, q, part, seq, j
 
 
 def from_tile(x: torch.Tensor, batch: int) -> torch.Tensor:
-    """Inverse of to_tile: [tiles, T, 2, 8, ns, 4, 2, 8, 4] -> [batch, T, 2, ns, 256]."""
+    """Inverse of to_tile: [tiles, T, 2, 8, ns, 4, parts, seqs, units] -> [batch, T, 2, ns, 256]."""
+    seqs, parts, units = _tile_geometry()
     tiles, t, ns = x.shape[0], x.shape[1], x.shape[4]
-    y = x.permute(0, 7, 1, 2, 4, 3, 6, 5, 8).reshape(tiles * GRU_TILE, t, 2, ns, GRU_H)
-    return y[:batch]
+    y = x.permute(0, 7, 1, 2, 4, 3, 5, 6, 8).reshape(tiles, seqs, t, 2, ns, 8, 4, 2, 4)   # .., w, q, s, i
+    return y.permute(0, 1, 2, 3, 4, 5, 7, 6, 8).reshape(tiles * seqs, t, 2, ns, GRU_H)[:batch]
 
 
 def from_pair_tile(x: torch.Tensor, batch: int):
-    """The pair-slot layout of the backward kernel's output, [tiles, T, 2, 8(w), 2(pair slot), 4(q), 2(s), 8(seq),
-    2(member), 4(i)] with slots (da_r|da_z), (da_n|da_n*r) -> (dgi [batch, T, 2, 3, 256] = (da_r, da_z, da_n),
-    dghn [batch, T, 2, 256] = da_n*r), both contiguous: exactly the bytes the host GEMMs read, copied once."""
+    """The pair-slot layout of the backward kernel's output, [tiles, T, 2, 8(w), 2(pair slot), 4(q), parts, seqs,
+    2(member), units] with slots (da_r|da_z), (da_n|da_n*r) -> (dgi [batch, T, 2, 3, 256] = (da_r, da_z, da_n),
+    dghn [batch, T, 2, 256] = da_n*r); the torch definition of what seld_gru_from_pair_tile does."""
+    seqs, parts, units = _tile_geometry()
     tiles, t = x.shape[0], x.shape[1]
-    src = x.permute(0, 7, 1, 2, 4, 8, 3, 6, 5, 9)          # tile, seq, T, dir, pair, member, w, s, q, i
-    dgi = torch.empty((tiles, GRU_TILE, t, 2, 3, 8, 2, 4, 4), dtype=x.dtype, device=x.device)
-    dghn = torch.empty((tiles, GRU_TILE, t, 2, 8, 2, 4, 4), dtype=x.dtype, device=x.device)
-    dgi[:, :, :, :, 0:2].copy_(src[:, :, :, :, 0])
-    dgi[:, :, :, :, 2].copy_(src[:, :, :, :, 1, 0])
-    dghn.copy_(src[:, :, :, :, 1, 1])
-    return (dgi.view(tiles * GRU_TILE, t, 2, 3, GRU_H)[:batch], dghn.view(tiles * GRU_TILE, t, 2, GRU_H)[:batch])
+    y = x.permute(0, 7, 1, 2, 4, 8, 3, 5, 6, 9).reshape(tiles, seqs, t, 2, 4, 8, 4, 2, 4)  # .., slot, w, q, s, i
+    y = y.permute(0, 1, 2, 3, 4, 5, 7, 6, 8).reshape(tiles * seqs, t, 2, 4, GRU_H)[:batch]
+    return y[:, :, :, :3].contiguous(), y[:, :, :, 3].contiguous()
 
 
 def to_tile_device(x: torch.Tensor, ns: int) -> torch.Tensor:
     """``to_tile`` by the HIP permute kernel (x: contiguous GPU tensor [B, T, 2, ns, 256], bf16 or fp32)."""
+    seqs, parts, units = _tile_geometry()
     b, t = x.shape[0], x.shape[1]
-    tiles = (b + GRU_TILE - 1) // GRU_TILE
+    tiles = (b + seqs - 1) // seqs
     x = x.contiguous()
-    out = torch.empty((tiles, t, 2, 8, ns, 4, 2, GRU_TILE, 4), dtype=x.dtype, device=x.device)
+    out = torch.empty((tiles, t, 2, 8, ns, 4, parts, seqs, units), dtype=x.dtype, device=x.device)
     with torch.cuda.device(ensure_init(x.device)):
         check(load_library().seld_gru_to_tile(_p(x), x.element_size(), b, t, ns, _p(out), _stream_ptr(x.device)),
               "seld_gru_to_tile")
@@ -459,7 +472,7 @@ def gru_forward(gi: torch.Tensor, w_hh: torch.Tensor, b_hn: torch.Tensor, need_s
         raise ValueError("gru_forward: b_hn must be [2, H]")
     y = torch.empty((tiles * GRU_TILE, t, 2 * h), dtype=gi.dtype, device=gi.device)
     saved_dtype = torch.float16 if gi.dtype == torch.bfloat16 else torch.float32      # see include/seld_hip.h
-    saved = torch.empty((tiles, t, 2, 8, 2, 64, 2, 4), dtype=saved_dtype, device=gi.device) \
+    saved = torch.empty((tiles, t, 2, 8, 2, 64, 2, 8 * GRU_TILE // 16), dtype=saved_dtype, device=gi.device) \
         if need_saved else None
     with torch.cuda.device(index):
         check(load_library().seld_gru_forward(_p(gi_tile), int(gi.dtype == torch.bfloat16), _p(w), _p(bias), tiles, t,
@@ -483,7 +496,8 @@ def gru_backward(dy: torch.Tensor, saved: torch.Tensor, y: torch.Tensor, w_hh: t
         y = torch.cat((y, y.new_zeros((tiles * GRU_TILE - b, t, h2))), dim=0)
     y = y.contiguous()
     w_t = w_hh.to(torch.bfloat16).transpose(1, 2).contiguous()            # [2, H, 3H]
-    dg_tile = torch.empty((tiles, t, 2, 8, 2, 4, 2, GRU_TILE, 2, 4), dtype=dy.dtype, device=dy.device)
+    dg_tile = torch.empty((tiles, t, 2, 8, 2, 4, 16 // GRU_TILE, GRU_TILE, 2, 8 * GRU_TILE // 16), dtype=dy.dtype,
+                          device=dy.device)
     dbias = torch.empty((tiles, 2, 4, h), dtype=torch.float32, device=dy.device)
     with torch.cuda.device(index):
         check(load_library().seld_gru_backward(_p(dy_tile), _p(saved), _p(y), int(dy.dtype == torch.bfloat16),

@@ -35,8 +35,9 @@ def test_forward_matches_bf16_aware_oracle(gpu_device, batch, steps):
     b_hn = torch.stack([b_hh[d][2 * H:] for d in range(2)])
     y, saved = seld_native.gru_forward(gi.to(gpu_device), torch.stack(w_hh).to(gpu_device), b_hn.to(gpu_device), True)
     ref = ogru.bigru_layer(x, w_ih, b_ih, w_hh, b_hh, exact=False)
-    tiles = (batch + 7) // 8
-    assert tuple(y.shape) == (batch, steps, 2 * H) and tuple(saved.shape) == (tiles, steps, 2, 8, 2, 64, 2, 4)
+    seqs = seld_native.GRU_TILE                                   # sequences per workgroup (8 or 4)
+    tiles = (batch + seqs - 1) // seqs
+    assert tuple(y.shape) == (batch, steps, 2 * H) and tuple(saved.shape) == (tiles, steps, 2, 8, 2, 64, 2, seqs // 2)
     assert saved.dtype == torch.float32                     # fp32 build; the bf16 build saves IEEE fp16
     assert (y.cpu() - ref).abs().max().item() <= 2e-3
     exact = ogru.bigru_layer(x, w_ih, b_ih, w_hh, b_hh, exact=True)
@@ -98,8 +99,10 @@ def test_layout_converters_match_the_torch_permutes(gpu_device, batch, steps, ns
     g = torch.Generator().manual_seed(3)
     x = torch.randn(batch, steps, 2, ns, H, generator=g).to(dtype).to(gpu_device)
     assert torch.equal(seld_native.to_tile_device(x, ns), seld_native.to_tile(x, ns))
-    tiles = (batch + 7) // 8
-    dg = torch.randn(tiles, steps, 2, 8, 2, 4, 2, 8, 2, 4, generator=g).to(dtype).to(gpu_device)
+    assert torch.equal(seld_native.from_tile(seld_native.to_tile(x, ns), batch), x)
+    seqs = seld_native.GRU_TILE
+    tiles = (batch + seqs - 1) // seqs
+    dg = torch.randn(tiles, steps, 2, 8, 2, 4, 16 // seqs, seqs, 2, seqs // 2, generator=g).to(dtype).to(gpu_device)
     dgi, dghn = seld_native.from_pair_tile_device(dg, batch)
     ref_gi, ref_n = seld_native.from_pair_tile(dg, batch)
     assert torch.equal(dgi, ref_gi) and torch.equal(dghn, ref_n)
