@@ -167,7 +167,7 @@ def kernel_rooflines(device):
     """Every other hand-written kernel of the path against the roofline that bounds it, at the workload's shapes
     (batch 32 windows), timed with HIP events on the launch stream AFTER the timed region (not part of `value`).
     HBM kernels: algorithmic bytes per launch / duration vs the 8 TB/s peak.  The GRU recurrence runs on 8 CUs
-    (one per direction and 8-sequence tile): its 2*B*T*2*H*3H flop against those CUs' dense bf16 MFMA peak."""
+    (one per direction and 4-sequence tile): its 2*B*T*2*H*3H flop against those CUs' dense bf16 MFMA peak."""
     import seld_native as nat
     out = []
 
@@ -217,12 +217,12 @@ def kernel_rooflines(device):
     dy = torch.randn(BATCH, WINDOW, 2 * h, device=device).to(torch.bfloat16)
     y, saved = nat.gru_forward(gi, w_hh, b_hn, True)
     flop = 2.0 * BATCH * WINDOW * 2 * h * 3 * h
-    cus = 2 * ((BATCH + 7) // 8)
+    cus = 2 * ((BATCH + nat.GRU_TILE - 1) // nat.GRU_TILE)
     peak = MFMA_BF16_PEAK_TFLOPS * cus / 256.0
     for name, fn in (("seld::gru_forward_kernel (+ layout permute)", lambda: nat.gru_forward(gi, w_hh, b_hn, True)),
                      ("seld::gru_backward_kernel (+ layout permutes)", lambda: nat.gru_backward(dy, saved, y, w_hh))):
         sec = timeit(fn)
-        out.append({"kernel": name, "bound": f"mfma on {cus} CUs (one per direction and 8-sequence tile)",
+        out.append({"kernel": name, "bound": f"mfma on {cus} CUs (one per direction and 4-sequence tile)",
                     "achieved": flop / sec / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flop / sec / 1e12 / peak,
                     "us_per_step": sec * 1e6 / WINDOW, "avg_launch_ms": sec * 1e3})
     return out

@@ -6,34 +6,36 @@
 // steps per direction of
 //     gh = h W_hh^T + b_hh ;  r = s(gi_r + gh_r) ; z = s(gi_z + gh_z) ; n = tanh(gi_n + r*gh_n)
 //     h' = (1 - z) n + z h
-// which a library executes as ~2 tiny kernels per step.  Here ONE workgroup per (direction,
-// 8-sequence batch tile) runs all T steps with W_hh resident on the CU:
+// which a library executes as ~2 tiny kernels per step.  Here ONE workgroup per (direction, kSeqs-sequence batch
+// tile) runs all T steps with W_hh resident on the CU:
 //   * 8 wavefronts; wavefront w owns hidden units [32w, 32w+32) for all three gates;
 //   * W_hh (bf16, 393 KB per direction) does not fit one place: the r and z gate rows live in
 //     VGPRs as MFMA A-fragments (128 registers per lane), the n gate rows in LDS (128 KB) laid
 //     out fragment-major so every ds_read_b128 is a linear conflict-free 1 KB read;
-//   * h_{t-1} (bf16) is exchanged through a double-buffered 16 x 256 LDS tile (row pitch 528 B:
+//   * h_{t-1} (bf16) is exchanged through a double-buffered kSeqs x 256 LDS tile (row pitch 528 B:
 //     conflict-free B-fragment reads), one barrier per step;
 //   * v_mfma_f32_16x16x32_bf16: per step 48 MFMAs per wavefront, fp32 accumulate, fp32 gates.
 //
-// WHY ONLY 8 SEQUENCES PER 16-COLUMN MFMA TILE.  With the weights resident, a step is bound by what ONE CU
+// WHY ONLY kSeqs = 4 SEQUENCES PER 16-COLUMN MFMA TILE.  With the weights resident, a step is bound by what ONE CU
 // can do besides the MFMAs: its vector-memory path sustains only ~10-15 B/clk (MI355X_MICROARCH.md: "~10
-// B/cyc/CU"), and the gate math (6 transcendentals per element) issues on the same 4 SIMDs.  Both scale
-// with sequences per CU while the MFMA time (96 per SIMD, ~1.5k cycles) does not -- so the batch is spread over
-// TWICE the CUs: columns 8..15 of every MFMA are padding (zero h rows), and after the MFMAs lane (q, c >= 8)
-// takes over the second 16-unit tile of lane (q, c - 8) with one DPP row-shift per value.  Every lane then
-// owns ONE (sequence, 4 units) group: half the gate instructions and half the bytes per CU per step, all 64
-// lanes active in every load and store.  Measured (B = 32, T = 250): see DESIGN.md section 5.4.
+// B/cyc/CU", stores issue-bound), and the gate math (6 transcendentals per element) issues on the same 4 SIMDs.
+// Both scale with sequences per CU while the MFMA time (96 per SIMD, ~1.5k cycles) does not -- so the batch is
+// spread over MORE CUs: the other columns of every MFMA are padding (they repeat a valid column), and after the
+// MFMAs the 16 / kSeqs lanes that share a sequence split the column's 2 x 4 accumulators among themselves with one
+// DPP row shift per value.  Every lane then owns ONE (sequence, kU units) group: a fraction of the gate
+// instructions and of the bytes per CU per step, all 64 lanes active in every load and store.  Measured
+// (B = 32, T = 250, us per step forward / backward): 16 sequences 1.68 / 3.33, 8 sequences 1.28 / 1.57,
+// 4 sequences 1.18 / 1.40.
 //
 // The backward kernel mirrors it: dgh (bf16) goes through LDS as the B operand, W_hh^T fragments
 // are register / LDS resident, dh is carried in registers; it emits the per-step gate gradients
-// from which the host forms dW_ih, dW_hh, dx with three large GEMMs.
+// from which the host forms dW_ih, dW_hh, dx with large GEMMs, and the bias gradients directly.
 #include <hip/hip_bf16.h>
 
 #include "seld_common.h"
 
 #ifndef SELD_GRU_SEQS
-#define SELD_GRU_SEQS 8
+#define SELD_GRU_SEQS 4
 #endif
 
 namespace seld {
