@@ -46,7 +46,22 @@ __global__ __launch_bounds__(kLossBlock) void softmax_mse_kernel(const void* __r
     const long cells_here = (n_cells - cell0) < kLossBlock ? (n_cells - cell0) : kLossBlock;
     const long elems = cells_here * M;
     // ---- coalesced load of the logits tile into LDS (as fp32)
-    if (kBf16) {
+    if (kBf16 && cells_here == kLossBlock) {
+      // full tile: 7168 B = 448 sixteen-byte pieces (the tile base is 16-byte aligned: 256 cells x 28 B)
+      const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(logits_) + cell0 * M);
+      for (int piece = tid; piece < kLossBlock * M / 8; piece += kLossBlock) {
+        const uint4 v = src[piece];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          f[2 * k] = __uint_as_float(w[k] << 16);
+          f[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+        }
+        *reinterpret_cast<float4*>(tile + piece * 8) = make_float4(f[0], f[1], f[2], f[3]);
+        *reinterpret_cast<float4*>(tile + piece * 8 + 4) = make_float4(f[4], f[5], f[6], f[7]);
+      }
+    } else if (kBf16) {
       const unsigned short* src = static_cast<const unsigned short*>(logits_) + cell0 * M;
       for (long i = tid * 2; i < elems; i += kLossBlock * 2) {   // elems is even (M = 14)
         const unsigned v = *reinterpret_cast<const unsigned*>(src + i);
@@ -121,7 +136,19 @@ __global__ __launch_bounds__(kLossBlock) void softmax_mse_kernel(const void* __r
         for (int c = 0; c < M; c += 2) *reinterpret_cast<float2*>(tile + tid * M + c) = make_float2(g[c], g[c + 1]);
       }
       __syncthreads();
-      if (kBf16) {
+      if (kBf16 && cells_here == kLossBlock) {
+        uint4* dst = reinterpret_cast<uint4*>(static_cast<unsigned short*>(grad_) + cell0 * M);
+        for (int piece = tid; piece < kLossBlock * M / 8; piece += kLossBlock) {
+          const float4 a = *reinterpret_cast<const float4*>(tile + piece * 8);
+          const float4 b = *reinterpret_cast<const float4*>(tile + piece * 8 + 4);
+          uint4 v;
+          v.x = float_to_bf16_bits(a.x) | (static_cast<unsigned>(float_to_bf16_bits(a.y)) << 16);
+          v.y = float_to_bf16_bits(a.z) | (static_cast<unsigned>(float_to_bf16_bits(a.w)) << 16);
+          v.z = float_to_bf16_bits(b.x) | (static_cast<unsigned>(float_to_bf16_bits(b.y)) << 16);
+          v.w = float_to_bf16_bits(b.z) | (static_cast<unsigned>(float_to_bf16_bits(b.w)) << 16);
+          dst[piece] = v;
+        }
+      } else if (kBf16) {
         unsigned short* dst = static_cast<unsigned short*>(grad_) + cell0 * M;
         for (long i = tid * 2; i < elems; i += kLossBlock * 2) {
           const unsigned lo = float_to_bf16_bits(tile[i]);

@@ -10,6 +10,8 @@ model_conformer.py:58-62.
 """
 import torch
 import torch.nn as nn
+
+from seld_linear import SeldLinear
 import torch.nn.functional as F
 
 from model_crnn import ConvBlock, build_cnn_encoder, run_cnn_encoder  # noqa: F401
@@ -25,9 +27,9 @@ class FeedForward(nn.Module):
 
     def __init__(self, d_model, d_ff=2048, dropout=0.1):
         super().__init__()
-        self.linear1 = nn.Linear(d_model, d_ff)
+        self.linear1 = SeldLinear(d_model, d_ff)
         self.dropout = nn.Dropout(dropout)
-        self.linear2 = nn.Linear(d_ff, d_model)
+        self.linear2 = SeldLinear(d_ff, d_model)
         self.norm = nn.LayerNorm(d_model)
         self.swish = Swish()
 
@@ -45,10 +47,10 @@ class MultiHeadSelfAttention(nn.Module):
         self.n_heads = n_heads
         self.head_dim = d_model // n_heads
         assert self.head_dim * n_heads == d_model, "d_model must be divisible by n_heads"
-        self.w_q = nn.Linear(d_model, d_model)
-        self.w_k = nn.Linear(d_model, d_model)
-        self.w_v = nn.Linear(d_model, d_model)
-        self.w_o = nn.Linear(d_model, d_model)
+        self.w_q = SeldLinear(d_model, d_model)
+        self.w_k = SeldLinear(d_model, d_model)
+        self.w_v = SeldLinear(d_model, d_model)
+        self.w_o = SeldLinear(d_model, d_model)
         self.dropout = nn.Dropout(dropout)
         self.norm = nn.LayerNorm(d_model)
 
@@ -114,17 +116,17 @@ class SELD_Conformer(nn.Module):
         self.num_classes = num_classes
         self.cnn_blocks, self.cnn_out_channels, self.cnn_out_freq = build_cnn_encoder(n_channels, n_mels, cnn_channels)
         self.cnn_feat_size = self.cnn_out_channels * self.cnn_out_freq
-        self.proj = nn.Linear(self.cnn_feat_size, conf_d_model)
+        self.proj = SeldLinear(self.cnn_feat_size, conf_d_model)
         self.conformer_blocks = nn.ModuleList([
             ConformerBlock(d_model=conf_d_model, n_heads=conf_n_heads, d_ff=conf_d_model * 4,
                            kernel_size=conf_kernel_size, dropout=dropout)
             for _ in range(conf_n_layers)])
         self.fnn = nn.Sequential(
-            nn.Linear(conf_d_model, 512),
+            SeldLinear(conf_d_model, 512),
             nn.LayerNorm(512),
             nn.ReLU(),
             nn.Dropout(dropout),
-            nn.Linear(512, self.grid_cells * num_classes),
+            SeldLinear(512, self.grid_cells * num_classes),
         )
 
     def forward(self, x):

@@ -12,6 +12,7 @@ hipBLASLt, set up by the trainer) and the recurrence runs in the persistent HIP 
 import torch
 import torch.nn as nn
 
+from seld_linear import SeldLinear
 from seld_rnn import SeldGRU
 
 
@@ -74,11 +75,11 @@ class SELD_CRNN(nn.Module):
                            batch_first=True, bidirectional=True, dropout=dropout if rnn_layers > 1 else 0)
         self.rnn_out_size = rnn_hidden * 2
         self.fnn = nn.Sequential(
-            nn.Linear(self.rnn_out_size, 512),
+            SeldLinear(self.rnn_out_size, 512),
             nn.LayerNorm(512),
             nn.ReLU(),
             nn.Dropout(dropout),
-            nn.Linear(512, self.grid_cells * num_classes),
+            SeldLinear(512, self.grid_cells * num_classes),
         )
 
     def forward(self, x):

@@ -9,6 +9,8 @@ The encoder is the torchvision ResNet-50 layout ([3, 4, 6, 3] bottlenecks, expan
 import torch
 import torch.nn as nn
 
+from seld_linear import SeldLinear
+
 from model_conformer import ConformerBlock
 
 
@@ -77,18 +79,18 @@ class SELD_ResNet50_Conformer(nn.Module):
         self.num_classes = num_classes
         self.encoder = ResNet50Encoder(in_channels=n_channels)
         self.enc_feat_dim = self.encoder.out_channels * (n_mels // 32)
-        self.proj = nn.Linear(self.enc_feat_dim, conf_d_model)
+        self.proj = SeldLinear(self.enc_feat_dim, conf_d_model)
         self.dropout = nn.Dropout(dropout)
         self.conformer_blocks = nn.ModuleList([
             ConformerBlock(d_model=conf_d_model, n_heads=conf_n_heads, d_ff=conf_d_model * 4,
                            kernel_size=conf_kernel_size, dropout=dropout)
             for _ in range(conf_n_layers)])
         self.head = nn.Sequential(
-            nn.Linear(conf_d_model, 1024),
+            SeldLinear(conf_d_model, 1024),
             nn.LayerNorm(1024),
             nn.ReLU(),
             nn.Dropout(dropout),
-            nn.Linear(1024, self.grid_cells * num_classes),
+            SeldLinear(1024, self.grid_cells * num_classes),
         )
 
     def forward(self, x):

@@ -11,6 +11,7 @@ import torch
 import torch.nn.functional as F
 
 import seld_native
+from seld_linear import tall_product
 
 HIDDEN = 256
 
@@ -51,7 +52,7 @@ class _BiGRULayer(torch.autograd.Function):
             dgi2 = dgi.view(n, 6 * h)                                             # d/d(gi), both directions
             x2 = xc.reshape(n, -1)
             dx = (dgi2 @ w_ih.to(cdt)).view_as(xc)
-            dw_ih = _tall_product(dgi2, x2)                                       # [6H, In] fp32
+            dw_ih = tall_product(dgi2, x2)                                       # [6H, In] fp32
             db_ih = dbias[:, :3].reshape(-1)
             db_hh = torch.cat((dbias[:, :2], dbias[:, 3:]), dim=1).reshape(2, 3 * h)
             # h_{t-1} of the forward recurrence: y shifted by one step in each direction's own time order
@@ -65,28 +66,12 @@ class _BiGRULayer(torch.autograd.Function):
             # d/d(gh) = (da_r, da_z, da_n * r).  Two well-shaped products instead of eight skinny ones: all of dgi
             # and dghn against both directions' h_prev; the wanted blocks are those with matching directions (the
             # cross-direction blocks and dgi's n rows are computed and dropped: ~6 GFLOP, cheaper than the launches).
-            p_gi = _tall_product(dgi2, hp).view(2, 3, h, 2, h)                    # [dir, gate, unit, dir', unit']
-            p_n = _tall_product(dghn.view(n, 2 * h), hp).view(2, h, 2, h)
+            p_gi = tall_product(dgi2, hp).view(2, 3, h, 2, h)                    # [dir, gate, unit, dir', unit']
+            p_n = tall_product(dghn.view(n, 2 * h), hp).view(2, h, 2, h)
             dw_hh = torch.stack([torch.cat((p_gi[d, :2, :, d].reshape(2 * h, h), p_n[d, :, d]), dim=0)
                                  for d in range(2)], dim=0)
         return dx.to(dy.dtype) if dx.dtype != dy.dtype and not torch.is_autocast_enabled() else dx, \
             dw_ih.to(w_ih.dtype), db_ih.to(w_ih.dtype), dw_hh.to(w_hh.dtype), db_hh.to(w_hh.dtype)
-
-
-def _tall_product(a, c, min_tiles=256):
-    """a^T c for tall operands (a [N, G], c [N, K], N = B*T = 8000 rows) -> [G, K] fp32.  When the output is too
-    small to fill the GPU with 128 x 128 tiles the rows are split into chunks multiplied as one batched GEMM
-    (transposed views, no copies) and the partial products are added in fp32."""
-    n, g = a.shape
-    k = c.shape[1]
-    chunks = 1
-    while chunks < 16 and chunks * ((g + 127) // 128) * ((k + 127) // 128) < min_tiles and n % (2 * chunks) == 0:
-        chunks *= 2
-    if chunks == 1:
-        return (a.t() @ c).float()
-    av = a.unflatten(0, (chunks, n // chunks)).transpose(1, 2)                    # [chunks, G, N/chunks] view
-    cv = c.unflatten(0, (chunks, n // chunks))
-    return torch.bmm(av, cv).float().sum(dim=0)
 
 
 class _Joined(torch.autograd.Function):

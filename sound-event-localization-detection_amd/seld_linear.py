@@ -1,0 +1,62 @@
+"""``nn.Linear`` with the reference's parameter names whose WEIGHT GRADIENT is shaped for the GPU.
+
+Every Linear of the SELD models sees B*T = 8000 rows (model_crnn.py:77-83, model_conformer.py:28-51,117-127,
+resnet50_model.py:80-91).  Its weight gradient  dW = dY^T X  is then a [out, in] matrix -- as small as 256 x 256 --
+reduced over 8000 rows: one library GEMM launches a handful of 64 x 64 tiles that each walk the whole reduction
+(measured 54 us for 4 GFLOP; 18 such GEMMs per Conformer iteration).  ``tall_product`` splits the rows into chunks
+multiplied as ONE batched GEMM on transposed views (no copies) and adds the partial products in fp32.  Forward and
+input gradient are the stock GEMMs.  On a CPU tensor (the reference's plumbing case) this is ``nn.Linear`` itself.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+enabled = True
+
+
+def tall_product(a, c, min_tiles=256, max_chunks=16):
+    """a^T c for tall operands (a [N, G], c [N, K]) -> [G, K] fp32.  Row strides may be anything (column stride 1)."""
+    n, g = a.shape
+    k = c.shape[1]
+    chunks = 1
+    while (chunks < max_chunks and chunks * ((g + 127) // 128) * ((k + 127) // 128) < min_tiles
+           and n % (2 * chunks) == 0 and n // (2 * chunks) >= 64):
+        chunks *= 2
+    if chunks == 1:
+        return (a.t() @ c).float()
+    av = a.unflatten(0, (chunks, n // chunks)).transpose(1, 2)                    # [chunks, G, N/chunks] view
+    cv = c.unflatten(0, (chunks, n // chunks))
+    return torch.bmm(av, cv).float().sum(dim=0)
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
+        with torch.autocast(device_type="cuda", enabled=False):
+            xc, wc = x.to(cdt), weight.to(cdt)
+            y = F.linear(xc, wc, None if bias is None else bias.to(cdt))
+        ctx.save_for_backward(xc, wc)
+        ctx.has_bias = bias is not None
+        ctx.in_dtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, grad):
+        xc, wc = ctx.saved_tensors
+        with torch.autocast(device_type="cuda", enabled=False):
+            g2 = grad.reshape(-1, grad.shape[-1]).to(xc.dtype)
+            x2 = xc.reshape(-1, xc.shape[-1])
+            dx = (g2 @ wc).view_as(xc) if ctx.needs_input_grad[0] else None
+            dw = tall_product(g2, x2) if ctx.needs_input_grad[1] else None
+            db = torch.sum(g2, dim=0, dtype=torch.float32) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        if dx is not None and dx.dtype != ctx.in_dtype:
+            dx = dx.to(ctx.in_dtype)
+        return dx, dw, db
+
+
+class SeldLinear(nn.Linear):
+    def forward(self, x):
+        if enabled and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.dim() >= 2:
+            return _Linear.apply(x, self.weight, self.bias)
+        return super().forward(x)

@@ -1,0 +1,51 @@
+"""GPU parity for SeldLinear (seld_linear.py): the split-K weight gradient against stock nn.Linear autograd
+(model_crnn.py:77-83, model_conformer.py:28-51).  Floating point: fp32 <= 1e-5 relative; bf16 autocast within the
+rounding of the stock bf16 path (both compared with an fp32 reference)."""
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("rows,fin,fout,bias", [((32, 250), 512, 512, True), ((8000,), 256, 1024, True),
+                                                ((3, 7), 64, 9072, True), ((32, 250), 2048, 256, False)])
+def test_fp32_matches_stock_linear(gpu_device, rows, fin, fout, bias):
+    from seld_linear import SeldLinear
+    torch.manual_seed(0)
+    mine = SeldLinear(fin, fout, bias=bias).to(gpu_device)
+    stock = nn.Linear(fin, fout, bias=bias).to(gpu_device)
+    stock.load_state_dict(mine.state_dict())
+    x = torch.randn(*rows, fin, device=gpu_device, requires_grad=True)
+    xr = x.detach().clone().requires_grad_(True)
+    y, yr = mine(x), stock(xr)
+    assert torch.allclose(y, yr, rtol=1e-5, atol=1e-5)
+    go = torch.randn_like(y)
+    y.backward(go)
+    yr.backward(go)
+    for a, b, name in [(x.grad, xr.grad, "dx"), (mine.weight.grad, stock.weight.grad, "dW")] + \
+            ([(mine.bias.grad, stock.bias.grad, "db")] if bias else []):
+        scale = b.abs().max().item() + 1e-12
+        assert (a - b).abs().max().item() <= 2e-5 * scale, name
+
+
+def test_bf16_autocast_tracks_fp32_reference(gpu_device):
+    from seld_linear import SeldLinear, tall_product
+    torch.manual_seed(1)
+    mine = SeldLinear(512, 512).to(gpu_device)
+    x = torch.randn(32, 250, 512, device=gpu_device, requires_grad=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = mine(x)
+    assert y.dtype == torch.bfloat16
+    go = torch.randn_like(y)
+    y.backward(go)
+    ref_w = go.float().reshape(-1, 512).t() @ x.detach().reshape(-1, 512)
+    assert mine.weight.grad.dtype == torch.float32
+    assert (mine.weight.grad - ref_w).abs().max().item() <= 2e-2 * ref_w.abs().max().item()
+    # the chunked product itself, strided operands (row stride > width), odd shapes fall back to one GEMM
+    a = torch.randn(8000, 2048, device=gpu_device)[:, :768]
+    c = torch.randn(8000, 512, device=gpu_device)[:, :256]
+    assert torch.allclose(tall_product(a, c), a.t() @ c, rtol=1e-4, atol=1e-2)
+    a = torch.randn(77, 33, device=gpu_device)
+    c = torch.randn(77, 5, device=gpu_device)
+    assert torch.allclose(tall_product(a, c), a.t() @ c, rtol=1e-5, atol=1e-5)
