@@ -17,6 +17,11 @@ HIDDEN = 256
 
 
 def applicable(module, x):
+    # fp32 runs (no autocast) keep the stock fp32 nn.GRU so that the "<= 1e-3 relative on logits" bar of fp32 parity
+    # runs holds: the HIP recurrence feeds bf16 operands to the MFMA.  ``module.allow_fp32 = True`` opts in.
+    low = torch.is_autocast_enabled() or x.dtype in (torch.bfloat16, torch.float16)
+    if not low and not getattr(module, "allow_fp32", False):
+        return False
     return (module.hidden_size == HIDDEN and module.bidirectional and module.batch_first and module.bias
             and x.dim() == 3 and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and module.proj_size == 0)
 

@@ -51,6 +51,8 @@ def test_module_forward_and_backward(gpu_device):
     torch.manual_seed(5)
     m = SeldGRU(input_size=96, hidden_size=H, num_layers=1, batch_first=True, bidirectional=True).to(gpu_device)
     x = torch.randn(6, 40, 96, device=gpu_device, requires_grad=True)
+    assert not seld_gru.applicable(m, x)            # fp32 without autocast keeps the stock fp32 nn.GRU ...
+    m.allow_fp32 = True                             # ... unless opted in (fp32 build of the kernel, bf16 MFMA operands)
     assert seld_gru.applicable(m, x)
     y, h_n = m(x)
     assert tuple(y.shape) == (6, 40, 2 * H) and tuple(h_n.shape) == (2, 6, H)

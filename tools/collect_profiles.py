@@ -29,6 +29,11 @@ if stats.exists():
         if (src_prof / name).exists():
             text = [l for l in open(src_prof / name) if l.startswith("{")]
             (out / f"{tag}_bench_under_rocprof.json").write_text("".join(text))
+timed = src_prof / "bench_timed_region_stats.csv"
+if timed.exists():                      # the timed region only (MIOpen find-mode trials of the warm-up excluded)
+    shutil.copy(timed, out / f"{tag}_bench_timed_region_stats.csv")
+    if (src_prof / "timed_region.log").exists():
+        shutil.copy(src_prof / "timed_region.log", out / f"{tag}_bench_timed_region.txt")
 if src_pmc.exists():
     for p in sorted(src_pmc.glob("pass*.csv")):
         shutil.copy(p, out / f"{tag}_pmc_logmel_{p.name}")
