@@ -285,11 +285,18 @@ def main():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP extension has no CPU fallback)")
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; SELD_DIST_BACKEND=gloo is a rehearsal mode that lets several ranks share one GPU (RCCL refuses
+    # that) to exercise DDP with the HIP autograd functions on a single-GPU box -- never a measurement
+    backend = os.environ.get("SELD_DIST_BACKEND", "nccl")
+    index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(index)
+    device = torch.device("cuda", index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
     torch.backends.cudnn.benchmark = True
 
     hot = HotPath(args, device, rank, world)
