@@ -125,6 +125,11 @@ int seld_softmax_mse(const void* logits, int logits_is_bf16, const uint16_t* mas
                      int64_t n_cells, int num_classes, float grad_scale, float* loss_out, void* grad,
                      void* workspace, void* stream);
 
+/* data[0..n) *= *scale with the scale read from DEVICE memory (the upstream gradient autograd hands the loss):
+ * when it is exactly 1.0 -- what loss.backward() passes -- every block returns after one load and the data is not
+ * touched.  n must be a multiple of 8; data bf16 when is_bf16, else fp32, 16-byte aligned. */
+int seld_scale_by_device_scalar(void* data, int is_bf16, int64_t n, const float* scale, void* stream);
+
 /* ---- CNN block tail: BatchNorm2d -> ReLU -> MaxPool2d((1,2)) at model_crnn.py:5-17 (ConvBlock.forward) ---- */
 /* x: the convolution output in channels-last memory order = row-major [rows = B*T*F][C] (bf16 when is_bf16, else
  * fp32); the two frequency bins of a pooling pair are adjacent rows.  pool = 2: MaxPool2d((1,2)); pool = 1: no

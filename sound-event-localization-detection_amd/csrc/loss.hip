@@ -195,6 +195,35 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const double* __restri
   if (threadIdx.x == 0) out[0] = static_cast<float>(part[0] * inv_count);
 }
 
+// grad *= *scale, where the scale is a DEVICE scalar (the upstream gradient of the loss, known only to the stream).
+// loss.backward() hands the loss an upstream gradient of exactly 1: every block then returns after one load and the
+// 145 MB gradient is not touched again -- without the host ever reading the scalar.
+template <bool kBf16>
+__global__ __launch_bounds__(256) void scale_by_scalar_kernel(void* __restrict__ data, long n8,
+                                                              const float* __restrict__ scale) {
+  const float s = *scale;
+  if (s == 1.0f) return;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n8; i += static_cast<long>(gridDim.x) * 256) {
+    if (kBf16) {
+      uint4 v = static_cast<uint4*>(data)[i];
+      unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float lo = __uint_as_float(w[k] << 16) * s, hi = __uint_as_float(w[k] & 0xffff0000u) * s;
+        w[k] = float_to_bf16_bits(lo) | (static_cast<unsigned>(float_to_bf16_bits(hi)) << 16);
+      }
+      static_cast<uint4*>(data)[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+      float4* p = static_cast<float4*>(data) + 2 * i;
+      float4 a = p[0], b = p[1];
+      a.x *= s; a.y *= s; a.z *= s; a.w *= s;
+      b.x *= s; b.y *= s; b.z *= s; b.w *= s;
+      p[0] = a;
+      p[1] = b;
+    }
+  }
+}
+
 template <bool kBf16, bool kMaskLabels, bool kGrad>
 static void launch(unsigned blocks, hipStream_t stream, const void* logits, const uint16_t* mask, const float* dense,
                    long n_cells, float grad_scale, double* partials, void* grad) {
@@ -207,6 +236,26 @@ static void launch(unsigned blocks, hipStream_t stream, const void* logits, cons
 extern "C" {
 
 int64_t seld_softmax_mse_workspace_bytes(void) { return 4096 * sizeof(double); }
+
+int seld_scale_by_device_scalar(void* data, int is_bf16, int64_t n, const float* scale, void* stream_) {
+  using namespace seld;
+  DeviceState* st = current_state();
+  if (!st) return kErrNotInitialised;
+  if (n < 0 || n % 8 != 0) return fail(kErrInvalidArgument, "seld_scale_by_device_scalar: n must be a multiple of 8");
+  if (n == 0) return kOk;
+  if (!data || !scale) return fail(kErrInvalidArgument, "seld_scale_by_device_scalar: null pointer");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const long n8 = n / 8;
+  long blocks = (n8 + 255) / 256;
+  const long cap = static_cast<long>(st->num_cus > 0 ? st->num_cus : 256) * 8;
+  if (blocks > cap) blocks = cap;
+  if (is_bf16) hipLaunchKernelGGL(scale_by_scalar_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                                  stream, data, n8, scale);
+  else hipLaunchKernelGGL(scale_by_scalar_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream,
+                          data, n8, scale);
+  SELD_HIP_TRY(hipGetLastError());
+  return kOk;
+}
 
 int seld_softmax_mse(const void* logits, int logits_is_bf16, const uint16_t* mask, const float* dense_labels,
                      int64_t n_cells, int num_classes, float grad_scale, float* loss_out, void* grad,

@@ -29,9 +29,13 @@ class _FusedSoftmaxMSE(torch.autograd.Function):
         return loss
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
+        import seld_native
         (grad,) = ctx.saved_tensors
-        return grad * grad_out.to(grad.dtype), None
+        # the saved gradient is consumed exactly once: scale it in place by the upstream gradient (a device scalar;
+        # exactly 1 under loss.backward(), in which case the kernel returns without touching the 145 MB tensor)
+        return seld_native.scale_by_device_scalar_(grad, grad_out), None
 
 
 def mask_to_dense(mask, num_classes):

@@ -63,6 +63,7 @@ def _declare(lib):
     lib.seld_softmax_mse_workspace_bytes.restype = _i64
     lib.seld_softmax_mse_workspace_bytes.argtypes = []
     lib.seld_softmax_mse.argtypes = [_ptr, _int, _ptr, _ptr, _i64, _int, ctypes.c_float, _ptr, _ptr, _ptr, _ptr]
+    lib.seld_scale_by_device_scalar.argtypes = [_ptr, _int, _i64, _ptr, _ptr]
     lib.seld_conv_tail_workspace_floats.restype = _i64
     lib.seld_conv_tail_workspace_floats.argtypes = [_int]
     lib.seld_conv_tail_forward.argtypes = [_ptr, _int, _i64, _int, _int, _ptr, _ptr, _ptr, _ptr, ctypes.c_float,
@@ -324,6 +325,20 @@ def softmax_mse(logits: torch.Tensor, labels: torch.Tensor, grad_scale: float | 
                                               _p(_workspace(logits.device)), _stream_ptr(logits.device)),
               "seld_softmax_mse")
     return loss[0], grad
+
+
+def scale_by_device_scalar_(data: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """data *= scale (a one-element fp32 GPU tensor) in place, without reading the scalar on the host; a scale of
+    exactly 1.0 costs one empty launch.  Falls back to torch when the layout does not fit the kernel."""
+    if (not data.is_cuda or data.dtype not in (torch.float32, torch.bfloat16) or not data.is_contiguous()
+            or data.numel() % 8 or data.data_ptr() % 16 or scale.numel() != 1):
+        return data.mul_(scale.to(data.dtype))
+    scale = scale.reshape(1).to(device=data.device, dtype=torch.float32)
+    with torch.cuda.device(ensure_init(data.device)):
+        check(load_library().seld_scale_by_device_scalar(_p(data), int(data.dtype == torch.bfloat16), data.numel(),
+                                                         _p(scale), _stream_ptr(data.device)),
+              "seld_scale_by_device_scalar")
+    return data
 
 
 # --------------------------------------------------------------------------- CNN block tail (BN + ReLU + pool)

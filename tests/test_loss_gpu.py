@@ -63,3 +63,24 @@ def test_bf16_logits_and_ragged_tail(gpu_device):
             assert grad.dtype == dt
             tol = 1e-5 if dt == torch.float32 else 8e-3
             assert (grad.float() - lref.grad).abs().max().item() <= tol * max(1.0, lref.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_module_backward_with_and_without_upstream_scale(gpu_device, dtype):
+    """SMRSELDLoss through autograd: loss.backward() (upstream gradient exactly 1: the scaling kernel must leave the
+    gradient untouched) and (0.37 * loss).backward() (scaled in place by the device scalar)."""
+    import loss as loss_mod
+    g = torch.Generator().manual_seed(9)
+    logits = (torch.randn(2, 30, 648, 14, generator=g) * 2).to(gpu_device).to(dtype)
+    mask = torch.randint(0, 1 << 13, (2, 30, 648), generator=g).to(torch.uint16).to(gpu_device)
+    dense = loss_mod.mask_to_dense(mask, 14)
+    crit = loss_mod.SMRSELDLoss("mse", 1.0, grid_size=(18, 36))
+    for factor in (1.0, 0.37):
+        a = logits.clone().requires_grad_(True)
+        total, _ = crit.loss_tensor(a, mask)
+        (total * factor if factor != 1.0 else total).backward()
+        b = logits.float().clone().requires_grad_(True)
+        ref = torch.nn.functional.mse_loss(torch.softmax(b, -1), dense) * factor
+        ref.backward()
+        tol = 1e-4 if dtype == torch.float32 else 1e-2
+        assert (a.grad.float() - b.grad).abs().max().item() <= tol * b.grad.abs().max().item(), factor
