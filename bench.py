@@ -66,6 +66,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="crnn", choices=["crnn", "conformer", "resnet_conformer"])
     ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (parity runs)")
+    ap.add_argument("--features", default="logmel", choices=["logmel", "logmel_iv", "logmel_gcc"],
+                    help="feature set (logmel = the reference; logmel_gcc with --channels 8 = BASELINE configs[3]'s "
+                         "per-GPU shard: 8-ch MIC, 8 log-mel + 28 GCC-PHAT input channels)")
+    ap.add_argument("--channels", type=int, default=4, help="audio channels of the synthetic clips")
     return ap.parse_args()
 
 
@@ -84,10 +88,10 @@ def synth_metadata(clip_idx: int, meta_frames: int = 600) -> np.ndarray:
     return np.asarray(rows, dtype=np.int64).reshape(-1, 5)
 
 
-def synth_clip_batch(seed: int, device):
+def synth_clip_batch(seed: int, device, channels=CHANNELS):
     """Seeded synthetic inputs: PCM ~ N(0, 0.1^2) clipped to [-1, 1); STARSS22-style metadata."""
     g = torch.Generator(device=device).manual_seed(1234 + seed)
-    pcm = (torch.randn(CLIPS_PER_STEP, CHANNELS, CLIP_SAMPLES, generator=g, device=device) * 0.1)
+    pcm = (torch.randn(CLIPS_PER_STEP, channels, CLIP_SAMPLES, generator=g, device=device) * 0.1)
     pcm.clamp_(-1.0, 1.0 - 2.0 ** -15)
     events = []
     for i in range(CLIPS_PER_STEP):
@@ -108,16 +112,19 @@ class HotPath:
         cfg.BATCH_SIZE = BATCH
         cfg.AMP_DTYPE = "fp32" if args.fp32 else "bf16"
         torch.manual_seed(0)
-        model = trainer.prepare_model_for_device(trainer.build_model((18, 36)), device)
+        self.features, self.channels = args.features, args.channels
+        extra = {"logmel": 0, "logmel_iv": 3, "logmel_gcc": args.channels * (args.channels - 1) // 2}[args.features]
+        self.feature_channels = args.channels + extra
+        model = trainer.prepare_model_for_device(trainer.build_model((18, 36), n_channels=self.feature_channels), device)
         self.model = trainer.wrap_ddp(model, device, world)
         weights = torch.ones(14, device=device)
         weights[13] = 0.05
         self.criterion = trainer.SMRSELDLoss(loss_type="mse", w_class=1.0, grid_size=(18, 36), class_weights=weights)
         self.optimizer = trainer.make_optimizer(self.model, cfg.LEARNING_RATE, device)
-        self.pcm, self.events = synth_clip_batch(rank, device)
+        self.pcm, self.events = synth_clip_batch(rank, device, args.channels)
         total = CLIPS_PER_STEP * FRAMES_PER_CLIP
         self.starts = torch.arange(0, total, HOP, dtype=torch.int64, device=device)          # 480 windows
-        self.spec_full = torch.empty(CLIPS_PER_STEP, 1 + CLIP_SAMPLES // 480, CHANNELS, 64, device=device)
+        self.spec_full = torch.empty(CLIPS_PER_STEP, 1 + CLIP_SAMPLES // 480, self.feature_channels, 64, device=device)
         self.mask_tm = torch.empty(total, 648, dtype=torch.uint16, device=device)
         self.feat_events = []          # (start, stop) HIP events around every log-mel launch
         self.model_events = []         # around the 15 optimiser iterations
@@ -128,14 +135,17 @@ class HotPath:
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        nat.logmel(self.pcm, layout="tcf", out=self.spec_full)
+        if self.features == "logmel":
+            nat.logmel(self.pcm, layout="tcf", out=self.spec_full)
+        else:                               # log-mel + STFT + intensity vectors / GCC-PHAT (csrc/spatial.hip)
+            self.spec_full = nat.spatial_features(self.pcm, self.features)
         if timed:
             e1.record()
             self.feat_events.append((e0, e1))
         for i, ev in enumerate(self.events):
             nat.rasterise_labels(ev, FRAMES_PER_CLIP, device=dev,
                                  out=self.mask_tm[i * FRAMES_PER_CLIP:(i + 1) * FRAMES_PER_CLIP])
-        spec_tm = self.spec_full[:, :FRAMES_PER_CLIP].reshape(-1, CHANNELS, 64)             # crop + concatenate
+        spec_tm = self.spec_full[:, :FRAMES_PER_CLIP].reshape(-1, self.feature_channels, 64)   # crop + concatenate
         if timed:
             m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             m0.record()
@@ -323,7 +333,9 @@ def main():
         feat_ms = float(np.mean([a.elapsed_time(b) for a, b in hot.feat_events]))
         model_ms = float(np.mean([a.elapsed_time(b) for a, b in hot.model_events]))
         clips = world * CLIPS_PER_STEP * args.steps
-        achieved_gbs = CLIPS_PER_STEP * BYTES_PER_CLIP / (feat_ms * 1e-3) / 1e9
+        frames = 1 + CLIP_SAMPLES // 480
+        bytes_per_clip = args.channels * CLIP_SAMPLES * 4 + hot.feature_channels * 64 * frames * 4
+        achieved_gbs = CLIPS_PER_STEP * bytes_per_clip / (feat_ms * 1e-3) / 1e9
         windows_per_step = CLIPS_PER_STEP * FRAMES_PER_CLIP // HOP
         model_tflops = windows_per_step * GFLOP_PER_WINDOW[args.model] / (model_ms * 1e-3) / 1e3
         traffic = measured_traffic_per_clip()
@@ -334,17 +346,23 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32" if args.fp32 else "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.model} FOA 4-ch 60s clips, bs={BATCH} windows (BASELINE configs[1])",
+            "config": {"workload": (f"{args.model} FOA 4-ch 60s clips, bs={BATCH} windows (BASELINE configs[1])"
+                                    if args.features == "logmel" and args.channels == 4 else
+                                    f"{args.model} {args.channels}-ch 60s clips, features {args.features} "
+                                    f"({hot.feature_channels} input channels), bs={BATCH} windows per GPU"),
                        "clips_per_step": CLIPS_PER_STEP, "windows_per_step": windows_per_step,
                        "optimizer_iterations_per_step": windows_per_step // BATCH,
                        "parallelism": f"dp{world}", "windows_per_s": clips * 60 / elapsed,
                        "final_loss": float(loss.item())},
-            "roofline": {"kernel": "seld::logmel_main_kernel<float> + logmel_edge_kernel<float> (fused STFT+mel+dB)", "bound": "hbm",
+            "roofline": {"kernel": "seld::logmel_main_kernel<float> + logmel_edge_kernel<float> (fused STFT+mel+dB)"
+                         if args.features == "logmel" else f"feature phase: log-mel + STFT + {args.features[7:]} kernels",
+                         "bound": "hbm",
                          "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic[1] * CLIPS_PER_STEP if traffic else None,
-                         "traffic_source": f"profiles/{traffic[0]} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)" if traffic else None,
-                         "bytes_per_launch": CLIPS_PER_STEP * BYTES_PER_CLIP, "avg_launch_ms": feat_ms,
+                         "traffic": traffic[1] * CLIPS_PER_STEP if traffic and args.features == "logmel" and args.channels == 4 else None,
+                         "traffic_source": f"profiles/{traffic[0]} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+                         if traffic and args.features == "logmel" and args.channels == 4 else None,
+                         "bytes_per_launch": CLIPS_PER_STEP * bytes_per_clip, "avg_launch_ms": feat_ms,
                          "features_only_clips_per_s": CLIPS_PER_STEP / (feat_ms * 1e-3)},
             "roofline_model": {"phase": f"{args.model} fwd+bwd+Adam, {windows_per_step // BATCH} iterations of {BATCH} windows",
                                "bound": "mfma", "achieved": model_tflops, "peak": MFMA_BF16_PEAK_TFLOPS,

@@ -143,13 +143,13 @@ int seld_scale_by_device_scalar(void* data, int is_bf16, int64_t n, const float*
  *   argmax are recomputed from x (first element wins ties, as max_pool2d).
  * workspace: seld_conv_tail_workspace_floats(C) floats of device scratch.  Deterministic (no float atomics). */
 int64_t seld_conv_tail_workspace_floats(int C);
-int seld_conv_tail_forward(const void* x, int is_bf16, int64_t rows, int C, int pool, const float* weight,
-                           const float* bias, float* running_mean, float* running_var, float momentum, float eps,
-                           int training, void* y, float* mean_invstd, float* scale_shift, float* workspace,
-                           void* stream);
-int seld_conv_tail_backward(const void* x, const void* dy, int is_bf16, int64_t rows, int C, int pool,
-                            const float* mean_invstd, const float* scale_shift, void* dx, float* dweight,
-                            float* dbias, float* workspace, void* stream);
+int seld_conv_tail_forward(const void* x, const void* residual, int is_bf16, int64_t rows, int C, int pool,
+                           const float* weight, const float* bias, float* running_mean, float* running_var,
+                           float momentum, float eps, int training, void* y, float* mean_invstd, float* scale_shift,
+                           float* workspace, void* stream);
+int seld_conv_tail_backward(const void* x, const void* residual, const void* dy, int is_bf16, int64_t rows, int C,
+                            int pool, const float* mean_invstd, const float* scale_shift, void* dx, void* dresidual,
+                            float* dweight, float* dbias, float* workspace, void* stream);
 
 /* ---- recurrence: nn.GRU(2048, 256, num_layers=2, bidirectional) at model_crnn.py:65-72 ------- */
 /* One bidirectional GRU layer's recurrence, all T steps in one launch (both directions), H = 256.

@@ -96,6 +96,9 @@ class Config:
     DDP_BUCKET_MB = 25          # RCCL all-reduce bucket size
     SYNC_BATCHNORM = False      # per-rank BN statistics by default
     SEED = None                 # the reference never seeds; set an int for reproducible runs
+    FEATURE_SET = "logmel"      # 'logmel' (the reference) | 'logmel_iv' (FOA: + 3 intensity-vector channels) |
+                                # 'logmel_gcc' (MIC array: + C(C-1)/2 GCC-PHAT channels); the model's n_channels
+                                # follows the dataset (4 -> 7, 8 -> 36)
     GAUSSIAN_AUGMENT = False    # smrl_seld_gaussian.py:397-534 label augmentation (+-2 sigma box per source)
     GAUSSIAN_SIGMA_AZIMUTH = 5.0
     GAUSSIAN_SIGMA_ELEVATION = 5.0

@@ -210,10 +210,15 @@ __global__ __launch_bounds__(kFinalThreads) void tail_stats_final_kernel(const v
   }
 }
 
+// kPool: 2 = MaxPool2d((1,2)) over adjacent rows; 1 = no pooling; 3 = no pooling + residual add before the ReLU
+// (the tail of a ResNet bottleneck, resnet50_model.py:30-52: relu(bn3(conv3(y)) + shortcut)); in mode 3 the second
+// operand row `x1` carries the residual, rounded into the activation dtype after the add like the unfused modules.
 template <typename T, int kPool>
-__global__ __launch_bounds__(kTailThreads) void tail_apply_kernel(const void* __restrict__ x, long out_rows, int C,
+__global__ __launch_bounds__(kTailThreads) void tail_apply_kernel(const void* __restrict__ x,
+                                                                  const void* __restrict__ res, long out_rows, int C,
                                                                   const float* __restrict__ scale_shift,
                                                                   void* __restrict__ y) {
+  constexpr int kStride = kPool == 2 ? 2 : 1;
   const int groups = C >> 3;
   const int cg = threadIdx.x % groups;
   const long slot = (static_cast<long>(blockIdx.x) * kTailThreads + threadIdx.x) / groups;
@@ -230,6 +235,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_apply_kernel(const void* __
     for (int i = 0; i < 8; ++i) {
       float z = Row8<T>::round(fmaf(x0[i], a[i], b[i]));
       if (kPool == 2) z = fmaxf(z, Row8<T>::round(fmaf(x1[i], a[i], b[i])));
+      if (kPool == 3) z = Row8<T>::round(z + x1[i]);
       out[i] = fmaxf(z, 0.0f);                     // max(relu(z0), relu(z1)) == relu(max(z0, z1))
     }
     Row8<T>::store(y, o * C + 8 * cg, out);
@@ -240,16 +246,18 @@ __global__ __launch_bounds__(kTailThreads) void tail_apply_kernel(const void* __
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const long oo = o + u * slots_total;
-      Row8<T>::load(x, (kPool * oo) * C + 8 * cg, x0[u]);
-      if (kPool == 2) Row8<T>::load(x, (kPool * oo + 1) * C + 8 * cg, x1[u]);
+      Row8<T>::load(x, (kStride * oo) * C + 8 * cg, x0[u]);
+      if (kPool == 2) Row8<T>::load(x, (kStride * oo + 1) * C + 8 * cg, x1[u]);
+      if (kPool == 3) Row8<T>::load(res, oo * C + 8 * cg, x1[u]);
     }
     one(x0[0], x1[0], o);
     one(x0[1], x1[1], o + slots_total);
   }
   for (; o < out_rows; o += slots_total) {
     float x0[8], x1[8];
-    Row8<T>::load(x, (kPool * o) * C + 8 * cg, x0);
-    if (kPool == 2) Row8<T>::load(x, (kPool * o + 1) * C + 8 * cg, x1);
+    Row8<T>::load(x, (kStride * o) * C + 8 * cg, x0);
+    if (kPool == 2) Row8<T>::load(x, (kStride * o + 1) * C + 8 * cg, x1);
+    if (kPool == 3) Row8<T>::load(res, o * C + 8 * cg, x1);
     one(x0, x1, o);
   }
 }
@@ -260,6 +268,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_apply_kernel(const void* __
 // and whether the ReLU lets it through.  Returns the receiving element's index (0 / 1) or -1.
 template <typename T, int kPool>
 __device__ __forceinline__ int route(float x0, float x1, float a, float b) {
+  if (kPool == 3) return fmaxf(Row8<T>::round(Row8<T>::round(fmaf(x0, a, b)) + x1), 0.0f) > 0.0f ? 0 : -1;
   const float r0 = fmaxf(Row8<T>::round(fmaf(x0, a, b)), 0.0f);
   if (kPool == 1) return r0 > 0.0f ? 0 : -1;
   const float r1 = fmaxf(Row8<T>::round(fmaf(x1, a, b)), 0.0f);
@@ -269,10 +278,12 @@ __device__ __forceinline__ int route(float x0, float x1, float a, float b) {
 
 template <typename T, int kPool>
 __global__ __launch_bounds__(kTailThreads) void tail_bwd_reduce_kernel(const void* __restrict__ x,
+                                                                       const void* __restrict__ res,
                                                                        const void* __restrict__ dy, long out_rows,
                                                                        int C, const float* __restrict__ scale_shift,
                                                                        const float* __restrict__ mean_invstd,
                                                                        float* __restrict__ partials) {
+  constexpr int kStride = kPool == 2 ? 2 : 1;
   __shared__ float lds[kTailThreads * 17];
   const int groups = C >> 3;
   const int cg = threadIdx.x % groups;
@@ -304,8 +315,9 @@ __global__ __launch_bounds__(kTailThreads) void tail_bwd_reduce_kernel(const voi
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const long oo = o + u * slots_total;
-      Row8<T>::load(x, (kPool * oo) * C + 8 * cg, x0[u]);
-      if (kPool == 2) Row8<T>::load(x, (kPool * oo + 1) * C + 8 * cg, x1[u]);
+      Row8<T>::load(x, (kStride * oo) * C + 8 * cg, x0[u]);
+      if (kPool == 2) Row8<T>::load(x, (kStride * oo + 1) * C + 8 * cg, x1[u]);
+      if (kPool == 3) Row8<T>::load(res, oo * C + 8 * cg, x1[u]);
       Row8<T>::load(dy, oo * C + 8 * cg, g[u]);
     }
     one(x0[0], x1[0], g[0]);
@@ -313,8 +325,9 @@ __global__ __launch_bounds__(kTailThreads) void tail_bwd_reduce_kernel(const voi
   }
   for (; o < out_rows; o += slots_total) {
     float x0[8], x1[8], g[8];
-    Row8<T>::load(x, (kPool * o) * C + 8 * cg, x0);
-    if (kPool == 2) Row8<T>::load(x, (kPool * o + 1) * C + 8 * cg, x1);
+    Row8<T>::load(x, (kStride * o) * C + 8 * cg, x0);
+    if (kPool == 2) Row8<T>::load(x, (kStride * o + 1) * C + 8 * cg, x1);
+    if (kPool == 3) Row8<T>::load(res, o * C + 8 * cg, x1);
     Row8<T>::load(dy, o * C + 8 * cg, g);
     one(x0, x1, g);
   }
@@ -362,10 +375,12 @@ __global__ __launch_bounds__(kFinalThreads) void tail_bwd_final_kernel(long rows
 
 template <typename T, int kPool>
 __global__ __launch_bounds__(kTailThreads) void tail_bwd_apply_kernel(const void* __restrict__ x,
+                                                                      const void* __restrict__ res,
                                                                       const void* __restrict__ dy, long out_rows,
                                                                       int C, const float* __restrict__ scale_shift,
                                                                       const float* __restrict__ coef,
-                                                                      void* __restrict__ dx) {
+                                                                      void* __restrict__ dx, void* __restrict__ dres) {
+  constexpr int kStride = kPool == 2 ? 2 : 1;
   const int groups = C >> 3;
   const int cg = threadIdx.x % groups;
   const long slot = (static_cast<long>(blockIdx.x) * kTailThreads + threadIdx.x) / groups;
@@ -389,9 +404,11 @@ __global__ __launch_bounds__(kTailThreads) void tail_bwd_apply_kernel(const void
         const float base1 = fmaf(q[i], x1[i], p[i]);
         d1[i] = sel == 1 ? fmaf(a[i], g[i], base1) : base1;
       }
+      if (kPool == 3) d1[i] = sel == 0 ? g[i] : 0.0f;
     }
-    Row8<T>::store(dx, (kPool * o) * C + 8 * cg, d0);
-    if (kPool == 2) Row8<T>::store(dx, (kPool * o + 1) * C + 8 * cg, d1);
+    Row8<T>::store(dx, (kStride * o) * C + 8 * cg, d0);
+    if (kPool == 2) Row8<T>::store(dx, (kStride * o + 1) * C + 8 * cg, d1);
+    if (kPool == 3) Row8<T>::store(dres, o * C + 8 * cg, d1);            // gradient of the residual = masked dy
   };
   long o = slot;
   for (; o + slots_total < out_rows; o += 2 * slots_total) {
@@ -399,8 +416,9 @@ __global__ __launch_bounds__(kTailThreads) void tail_bwd_apply_kernel(const void
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const long oo = o + u * slots_total;
-      Row8<T>::load(x, (kPool * oo) * C + 8 * cg, x0[u]);
-      if (kPool == 2) Row8<T>::load(x, (kPool * oo + 1) * C + 8 * cg, x1[u]);
+      Row8<T>::load(x, (kStride * oo) * C + 8 * cg, x0[u]);
+      if (kPool == 2) Row8<T>::load(x, (kStride * oo + 1) * C + 8 * cg, x1[u]);
+      if (kPool == 3) Row8<T>::load(res, oo * C + 8 * cg, x1[u]);
       Row8<T>::load(dy, oo * C + 8 * cg, g[u]);
     }
     one(x0[0], x1[0], g[0], o);
@@ -408,8 +426,9 @@ __global__ __launch_bounds__(kTailThreads) void tail_bwd_apply_kernel(const void
   }
   for (; o < out_rows; o += slots_total) {
     float x0[8], x1[8], g[8];
-    Row8<T>::load(x, (kPool * o) * C + 8 * cg, x0);
-    if (kPool == 2) Row8<T>::load(x, (kPool * o + 1) * C + 8 * cg, x1);
+    Row8<T>::load(x, (kStride * o) * C + 8 * cg, x0);
+    if (kPool == 2) Row8<T>::load(x, (kStride * o + 1) * C + 8 * cg, x1);
+    if (kPool == 3) Row8<T>::load(res, o * C + 8 * cg, x1);
     Row8<T>::load(dy, o * C + 8 * cg, g);
     one(x0, x1, g, o);
   }
@@ -438,7 +457,8 @@ extern "C" {
 
 int64_t seld_conv_tail_workspace_floats(int C) { return 2LL * seld::kTailStatBlocks * C + 2LL * C; }
 
-int seld_conv_tail_forward(const void* x, int is_bf16, int64_t rows, int C, int pool, const float* weight,
+int seld_conv_tail_forward(const void* x, const void* residual, int is_bf16, int64_t rows, int C, int pool,
+                           const float* weight,
                            const float* bias, float* running_mean, float* running_var, float momentum, float eps,
                            int training, void* y, float* mean_invstd, float* scale_shift, float* workspace,
                            void* stream_) {
@@ -446,6 +466,7 @@ int seld_conv_tail_forward(const void* x, int is_bf16, int64_t rows, int C, int 
   DeviceState* st = current_state();
   if (!st) return kErrNotInitialised;
   if (int rc = tail_check("seld_conv_tail_forward", rows, C, pool)) return rc;
+  if (residual && pool != 1) return fail(kErrUnsupported, "seld_conv_tail_forward: a residual needs pool = 1");
   if (!x || !y || !mean_invstd || !scale_shift || (training && !workspace))
     return fail(kErrInvalidArgument, "seld_conv_tail_forward: null pointer");
   if (!training && (!running_mean || !running_var))
@@ -467,22 +488,33 @@ int seld_conv_tail_forward(const void* x, int is_bf16, int64_t rows, int C, int 
                           momentum, eps, training, mean_invstd, scale_shift);
   const long out_rows = rows / pool;
   const dim3 grid(tail_grid(st, out_rows, C));
-#define SELD_TAIL_APPLY(T, P) \
-  hipLaunchKernelGGL((tail_apply_kernel<T, P>), grid, dim3(kTailThreads), 0, stream, x, out_rows, C, scale_shift, y)
-  if (is_bf16) { if (pool == 2) SELD_TAIL_APPLY(__hip_bfloat16, 2); else SELD_TAIL_APPLY(__hip_bfloat16, 1); }
-  else { if (pool == 2) SELD_TAIL_APPLY(float, 2); else SELD_TAIL_APPLY(float, 1); }
+  const int mode = residual ? 3 : pool;
+#define SELD_TAIL_APPLY(T, P)                                                                                     \
+  hipLaunchKernelGGL((tail_apply_kernel<T, P>), grid, dim3(kTailThreads), 0, stream, x, residual, out_rows, C, \
+                     scale_shift, y)
+  if (is_bf16) {
+    if (mode == 2) SELD_TAIL_APPLY(__hip_bfloat16, 2);
+    else if (mode == 3) SELD_TAIL_APPLY(__hip_bfloat16, 3);
+    else SELD_TAIL_APPLY(__hip_bfloat16, 1);
+  } else {
+    if (mode == 2) SELD_TAIL_APPLY(float, 2);
+    else if (mode == 3) SELD_TAIL_APPLY(float, 3);
+    else SELD_TAIL_APPLY(float, 1);
+  }
 #undef SELD_TAIL_APPLY
   SELD_HIP_TRY(hipGetLastError());
   return kOk;
 }
 
-int seld_conv_tail_backward(const void* x, const void* dy, int is_bf16, int64_t rows, int C, int pool,
-                            const float* mean_invstd, const float* scale_shift, void* dx, float* dweight,
-                            float* dbias, float* workspace, void* stream_) {
+int seld_conv_tail_backward(const void* x, const void* residual, const void* dy, int is_bf16, int64_t rows, int C,
+                            int pool, const float* mean_invstd, const float* scale_shift, void* dx, void* dresidual,
+                            float* dweight, float* dbias, float* workspace, void* stream_) {
   using namespace seld;
   DeviceState* st = current_state();
   if (!st) return kErrNotInitialised;
   if (int rc = tail_check("seld_conv_tail_backward", rows, C, pool)) return rc;
+  if ((residual != nullptr) != (dresidual != nullptr) || (residual && pool != 1))
+    return fail(kErrInvalidArgument, "seld_conv_tail_backward: residual and dresidual go together, with pool = 1");
   if (!x || !dy || !dx || !mean_invstd || !scale_shift || !dweight || !dbias || !workspace)
     return fail(kErrInvalidArgument, "seld_conv_tail_backward: null pointer");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -491,16 +523,24 @@ int seld_conv_tail_backward(const void* x, const void* dy, int is_bf16, int64_t 
   float* coef = workspace + 2L * nblocks * C;        // [2][C] after the partial sums
 #define SELD_TAIL_BWD(T, P)                                                                                      \
   do {                                                                                                           \
-    hipLaunchKernelGGL((tail_bwd_reduce_kernel<T, P>), dim3(nblocks), dim3(kTailThreads), 0, stream, x, dy,      \
-                       out_rows, C, scale_shift, mean_invstd, workspace);                                        \
+    hipLaunchKernelGGL((tail_bwd_reduce_kernel<T, P>), dim3(nblocks), dim3(kTailThreads), 0, stream, x, residual, \
+                       dy, out_rows, C, scale_shift, mean_invstd, workspace);                                    \
     hipLaunchKernelGGL(tail_bwd_final_kernel, dim3((C + kFinalChannels - 1) / kFinalChannels), dim3(kFinalThreads), \
                        0, stream, static_cast<long>(rows), C, workspace, nblocks, scale_shift, mean_invstd,      \
                        dweight, dbias, coef);                                                                    \
     hipLaunchKernelGGL((tail_bwd_apply_kernel<T, P>), dim3(tail_grid(st, out_rows, C)), dim3(kTailThreads), 0,   \
-                       stream, x, dy, out_rows, C, scale_shift, coef, dx);                                       \
+                       stream, x, residual, dy, out_rows, C, scale_shift, coef, dx, dresidual);                  \
   } while (0)
-  if (is_bf16) { if (pool == 2) SELD_TAIL_BWD(__hip_bfloat16, 2); else SELD_TAIL_BWD(__hip_bfloat16, 1); }
-  else { if (pool == 2) SELD_TAIL_BWD(float, 2); else SELD_TAIL_BWD(float, 1); }
+  const int mode = residual ? 3 : pool;
+  if (is_bf16) {
+    if (mode == 2) SELD_TAIL_BWD(__hip_bfloat16, 2);
+    else if (mode == 3) SELD_TAIL_BWD(__hip_bfloat16, 3);
+    else SELD_TAIL_BWD(__hip_bfloat16, 1);
+  } else {
+    if (mode == 2) SELD_TAIL_BWD(float, 2);
+    else if (mode == 3) SELD_TAIL_BWD(float, 3);
+    else SELD_TAIL_BWD(float, 1);
+  }
 #undef SELD_TAIL_BWD
   SELD_HIP_TRY(hipGetLastError());
   return kOk;

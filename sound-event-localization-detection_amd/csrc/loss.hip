@@ -32,23 +32,28 @@ template <int M, bool kBf16, bool kMaskLabels, bool kGrad>
 __global__ __launch_bounds__(kLossBlock) void softmax_mse_kernel(const void* __restrict__ logits_,
                                                                   const uint16_t* __restrict__ mask,
                                                                   const float* __restrict__ dense,
-                                                                  long n_cells, float grad_scale,
+                                                                  int n_cells, float grad_scale,
                                                                   double* __restrict__ partials,
                                                                   void* __restrict__ grad_) {
   __shared__ __attribute__((aligned(16))) float tile[kLossBlock * M];
   __shared__ double wave_sums[kLossBlock / 64];
   const int tid = threadIdx.x;
   double local = 0.0;
-  const long n_tiles = (n_cells + kLossBlock - 1) / kLossBlock;
+  // All index arithmetic is 32-bit on purpose (the host checks n_cells * M < 2^31).  With 64-bit extents hipcc
+  // (ROCm 7.2, gfx950) emitted, for some instantiations of this kernel, a v_cmp_lt_i64 followed by s_cselect
+  // WITHOUT copying VCC to SCC for `min(n_cells - cell0, 256)`: the ragged last tile was then processed as a full
+  // one and read 256 cells of whatever lies behind the logits / labels (wrong sums, NaN, or a memory fault).
+  // s_min_i32 cannot go wrong that way; tests/test_loss_gpu.py::test_every_variant_at_ragged_sizes covers it.
+  const int n_tiles = (n_cells + kLossBlock - 1) / kLossBlock;
 
-  for (long tileno = blockIdx.x; tileno < n_tiles; tileno += gridDim.x) {
-    const long cell0 = tileno * kLossBlock;
-    const long cells_here = (n_cells - cell0) < kLossBlock ? (n_cells - cell0) : kLossBlock;
-    const long elems = cells_here * M;
+  for (int tileno = blockIdx.x; tileno < n_tiles; tileno += gridDim.x) {
+    const int cell0 = tileno * kLossBlock;
+    const int cells_here = min(n_cells - cell0, kLossBlock);
+    const int elems = cells_here * M;
     // ---- coalesced load of the logits tile into LDS (as fp32)
     if (kBf16 && cells_here == kLossBlock) {
       // full tile: 7168 B = 448 sixteen-byte pieces (the tile base is 16-byte aligned: 256 cells x 28 B)
-      const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(logits_) + cell0 * M);
+      const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(logits_) + static_cast<long>(cell0) * M);
       for (int piece = tid; piece < kLossBlock * M / 8; piece += kLossBlock) {
         const uint4 v = src[piece];
         const unsigned w[4] = {v.x, v.y, v.z, v.w};
@@ -62,19 +67,19 @@ __global__ __launch_bounds__(kLossBlock) void softmax_mse_kernel(const void* __r
         *reinterpret_cast<float4*>(tile + piece * 8 + 4) = make_float4(f[4], f[5], f[6], f[7]);
       }
     } else if (kBf16) {
-      const unsigned short* src = static_cast<const unsigned short*>(logits_) + cell0 * M;
-      for (long i = tid * 2; i < elems; i += kLossBlock * 2) {   // elems is even (M = 14)
+      const unsigned short* src = static_cast<const unsigned short*>(logits_) + static_cast<long>(cell0) * M;
+      for (int i = tid * 2; i < elems; i += kLossBlock * 2) {   // elems is even (M = 14)
         const unsigned v = *reinterpret_cast<const unsigned*>(src + i);
         tile[i] = bf16_bits_to_float(static_cast<unsigned short>(v & 0xffffu));
         tile[i + 1] = bf16_bits_to_float(static_cast<unsigned short>(v >> 16));
       }
     } else {
-      const float* src = static_cast<const float*>(logits_) + cell0 * M;
+      const float* src = static_cast<const float*>(logits_) + static_cast<long>(cell0) * M;
       if ((cell0 * M) % 4 == 0 && elems % 4 == 0) {
-        for (long i = tid * 4; i < elems; i += kLossBlock * 4)
+        for (int i = tid * 4; i < elems; i += kLossBlock * 4)
           *reinterpret_cast<float4*>(tile + i) = *reinterpret_cast<const float4*>(src + i);
       } else {
-        for (long i = tid; i < elems; i += kLossBlock) tile[i] = src[i];
+        for (int i = tid; i < elems; i += kLossBlock) tile[i] = src[i];
       }
     }
     __syncthreads();
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(kLossBlock) void softmax_mse_kernel(const void* __r
         for (int c = 0; c < M; ++c) y[c] = ((m >> c) & 1u) ? 1.0f : 0.0f;
         if (m == 0u) y[M - 1] = 1.0f;                       // background rule, dataset.py:114-117
       } else {
-        const float* yp = dense + (cell0 + tid) * M;
+        const float* yp = dense + static_cast<long>(cell0 + tid) * M;
 #pragma unroll
         for (int c = 0; c < M; c += 2) {
           const float2 v = *reinterpret_cast<const float2*>(yp + c);
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(kLossBlock) void softmax_mse_kernel(const void* __r
       }
       __syncthreads();
       if (kBf16 && cells_here == kLossBlock) {
-        uint4* dst = reinterpret_cast<uint4*>(static_cast<unsigned short*>(grad_) + cell0 * M);
+        uint4* dst = reinterpret_cast<uint4*>(static_cast<unsigned short*>(grad_) + static_cast<long>(cell0) * M);
         for (int piece = tid; piece < kLossBlock * M / 8; piece += kLossBlock) {
           const float4 a = *reinterpret_cast<const float4*>(tile + piece * 8);
           const float4 b = *reinterpret_cast<const float4*>(tile + piece * 8 + 4);
@@ -149,19 +154,19 @@ __global__ __launch_bounds__(kLossBlock) void softmax_mse_kernel(const void* __r
           dst[piece] = v;
         }
       } else if (kBf16) {
-        unsigned short* dst = static_cast<unsigned short*>(grad_) + cell0 * M;
-        for (long i = tid * 2; i < elems; i += kLossBlock * 2) {
+        unsigned short* dst = static_cast<unsigned short*>(grad_) + static_cast<long>(cell0) * M;
+        for (int i = tid * 2; i < elems; i += kLossBlock * 2) {
           const unsigned lo = float_to_bf16_bits(tile[i]);
           const unsigned hi = float_to_bf16_bits(tile[i + 1]);
           *reinterpret_cast<unsigned*>(dst + i) = lo | (hi << 16);
         }
       } else {
-        float* dst = static_cast<float*>(grad_) + cell0 * M;
+        float* dst = static_cast<float*>(grad_) + static_cast<long>(cell0) * M;
         if ((cell0 * M) % 4 == 0 && elems % 4 == 0) {
-          for (long i = tid * 4; i < elems; i += kLossBlock * 4)
+          for (int i = tid * 4; i < elems; i += kLossBlock * 4)
             *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(tile + i);
         } else {
-          for (long i = tid; i < elems; i += kLossBlock) dst[i] = tile[i];
+          for (int i = tid; i < elems; i += kLossBlock) dst[i] = tile[i];
         }
       }
     }
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256) void scale_by_scalar_kernel(void* __restrict__
 
 template <bool kBf16, bool kMaskLabels, bool kGrad>
 static void launch(unsigned blocks, hipStream_t stream, const void* logits, const uint16_t* mask, const float* dense,
-                   long n_cells, float grad_scale, double* partials, void* grad) {
+                   int n_cells, float grad_scale, double* partials, void* grad) {
   hipLaunchKernelGGL((softmax_mse_kernel<14, kBf16, kMaskLabels, kGrad>), dim3(blocks), dim3(kLossBlock), 0, stream,
                      logits, mask, dense, n_cells, grad_scale, partials, grad);
 }
@@ -265,6 +270,8 @@ int seld_softmax_mse(const void* logits, int logits_is_bf16, const uint16_t* mas
   if (!st) return kErrNotInitialised;
   if (num_classes != 14) return fail(kErrUnsupported, "seld_softmax_mse: built for 14 classes (config.py:40)");
   if (n_cells <= 0) return fail(kErrInvalidArgument, "seld_softmax_mse: n_cells must be positive");
+  if (n_cells > (2147483647LL - 4096) / num_classes)
+    return fail(kErrUnsupported, "seld_softmax_mse: n_cells * num_classes must stay below 2^31 (32-bit tile indexing)");
   if (!logits || !loss_out || !workspace) return fail(kErrInvalidArgument, "seld_softmax_mse: null pointer");
   if ((mask == nullptr) == (dense_labels == nullptr))
     return fail(kErrInvalidArgument, "seld_softmax_mse: pass exactly one of mask / dense_labels");
@@ -276,7 +283,7 @@ int seld_softmax_mse(const void* logits, int logits_is_bf16, const uint16_t* mas
   double* partials = static_cast<double*>(workspace);
   const unsigned nb = static_cast<unsigned>(blocks);
   const bool bf = logits_is_bf16 != 0, mk = mask != nullptr, gr = grad != nullptr;
-  const long n = n_cells;
+  const int n = static_cast<int>(n_cells);
 #define SELD_DISPATCH(B, K, G) \
   if (bf == B && mk == K && gr == G) launch<B, K, G>(nb, stream, logits, mask, dense_labels, n, grad_scale, partials, grad)
   SELD_DISPATCH(false, false, false); SELD_DISPATCH(false, false, true);

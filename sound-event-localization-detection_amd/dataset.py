@@ -241,7 +241,7 @@ class SELDDataset(Dataset):
         """One recording -> (spec_tm [T, C, 64] f32, mask [T, 648] u16) on the device, cropped to the
         common frame count (dataset.py:224-249)."""
         data, rate, bits = _read_wav(audio_path)
-        if data.shape[0] != 4:
+        if data.shape[0] != 4 and getattr(config, "FEATURE_SET", "logmel") != "logmel_gcc":
             logger.warning(f"Expected 4 channels but got {data.shape[0]} channels in {audio_path}")
         if bits == 16:
             pcm = torch.from_numpy(data).to(self.device)                       # int16: half the PCIe / HBM bytes
@@ -252,7 +252,9 @@ class SELDDataset(Dataset):
     def _features_from_pcm(self, pcm, rate, rows):
         if int(rate) != self.sample_rate:
             raise NotImplementedError(f"sample rate {rate} != {self.sample_rate}: the feature kernel is built for 24 kHz")
-        spec = seld_native.logmel(pcm, layout="tcf")                           # [F, C, 64]
+        # [F, C_total, 64]: the reference's per-channel log-mel, optionally followed by the north-star additions
+        # (FOA intensity vectors / GCC-PHAT, csrc/spatial.hip) as extra input channels
+        spec = seld_native.spatial_features(pcm, getattr(config, "FEATURE_SET", "logmel"))
         audio_duration = pcm.shape[1] / rate                                   # dataset.py:232 (float64)
         if self.use_gaussian_augmentation:                                      # smrl_seld_gaussian.py:608-618
             mask, _, _ = augment_with_gaussian_mask(rows, audio_duration, self.I, self.J,

@@ -32,6 +32,16 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         shortcut = x if self.downsample is None else self.downsample(x)
+        if x.is_cuda:
+            import seld_convtail as tail           # fused BatchNorm -> [+ shortcut] -> ReLU (csrc/convtail.hip)
+            y = self.conv1(x)
+            y = tail.bn_relu(self.bn1, y) if tail.bn_applicable(self.bn1, y) else self.relu(self.bn1(y))
+            y = self.conv2(y)
+            y = tail.bn_relu(self.bn2, y) if tail.bn_applicable(self.bn2, y) else self.relu(self.bn2(y))
+            y = self.conv3(y)
+            if tail.bn_applicable(self.bn3, y) and shortcut.shape == y.shape and shortcut.dtype == y.dtype:
+                return tail.bn_relu(self.bn3, y, residual=shortcut)
+            return self.relu(self.bn3(y) + shortcut)
         y = self.relu(self.bn1(self.conv1(x)))
         y = self.relu(self.bn2(self.conv2(y)))
         y = self.bn3(self.conv3(y))
@@ -66,7 +76,13 @@ class ResNet50Encoder(nn.Module):
         return nn.Sequential(*stack)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.conv1(x)
+        if x.is_cuda:
+            import seld_convtail as tail
+            x = tail.bn_relu(self.bn1, x) if tail.bn_applicable(self.bn1, x) else self.relu(self.bn1(x))
+        else:
+            x = self.relu(self.bn1(x))
+        x = self.maxpool(x)
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
 

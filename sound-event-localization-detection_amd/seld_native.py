@@ -66,9 +66,10 @@ def _declare(lib):
     lib.seld_scale_by_device_scalar.argtypes = [_ptr, _int, _i64, _ptr, _ptr]
     lib.seld_conv_tail_workspace_floats.restype = _i64
     lib.seld_conv_tail_workspace_floats.argtypes = [_int]
-    lib.seld_conv_tail_forward.argtypes = [_ptr, _int, _i64, _int, _int, _ptr, _ptr, _ptr, _ptr, ctypes.c_float,
+    lib.seld_conv_tail_forward.argtypes = [_ptr, _ptr, _int, _i64, _int, _int, _ptr, _ptr, _ptr, _ptr, ctypes.c_float,
                                            ctypes.c_float, _int, _ptr, _ptr, _ptr, _ptr, _ptr]
-    lib.seld_conv_tail_backward.argtypes = [_ptr, _ptr, _int, _i64, _int, _int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]
+    lib.seld_conv_tail_backward.argtypes = [_ptr, _ptr, _ptr, _int, _i64, _int, _int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                            _ptr, _ptr]
     lib.seld_gru_to_tile.argtypes = [_ptr, _int, _i64, _i64, _int, _ptr, _ptr]
     lib.seld_gru_from_pair_tile.argtypes = [_ptr, _int, _i64, _i64, _ptr, _ptr, _ptr]
     lib.seld_gru_tile_rows.restype = _i64
@@ -357,10 +358,15 @@ def _tail_view(x: torch.Tensor):
     return b * t * f, c
 
 
-def conv_tail_forward(x, weight, bias, running_mean, running_var, momentum, eps, training, pool):
+def conv_tail_forward(x, weight, bias, running_mean, running_var, momentum, eps, training, pool, residual=None):
     """model_crnn.py:5-17 after the convolution: BatchNorm2d -> ReLU -> MaxPool2d((1, pool)) on a channels-last
-    [B, C, T, F] activation.  Returns (y [B, C, T, F // pool] channels-last, mean_invstd [2, C], scale_shift [2, C])."""
+    [B, C, T, F] activation; with ``residual`` (pool = 1): BatchNorm2d -> + residual -> ReLU (resnet50_model.py:30-52).
+    Returns (y [B, C, T, F // pool] channels-last, mean_invstd [2, C], scale_shift [2, C])."""
     rows, c = _tail_view(x)
+    if residual is not None:
+        if pool != 1 or residual.shape != x.shape or residual.dtype != x.dtype:
+            raise ValueError("conv_tail: the residual must match x and needs pool = 1")
+        _tail_view(residual)
     b, _, t, f = x.shape
     if f % pool:
         raise ValueError("conv_tail: the frequency extent must be a multiple of the pool width")
@@ -370,27 +376,31 @@ def conv_tail_forward(x, weight, bias, running_mean, running_var, momentum, eps,
     lib = load_library()
     ws = torch.empty(lib.seld_conv_tail_workspace_floats(c), dtype=torch.float32, device=x.device)
     with torch.cuda.device(index):
-        check(lib.seld_conv_tail_forward(_p(x), int(x.dtype == torch.bfloat16), rows, c, pool, _p(weight), _p(bias),
+        check(lib.seld_conv_tail_forward(_p(x), _p(residual), int(x.dtype == torch.bfloat16), rows, c, pool, _p(weight),
+                                         _p(bias),
                                          _p(running_mean), _p(running_var), float(momentum), float(eps), int(training),
                                          _p(y), _p(stats[0]), _p(stats[1]), _p(ws), _stream_ptr(x.device)),
               "seld_conv_tail_forward")
     return y, stats[0], stats[1]
 
 
-def conv_tail_backward(x, dy, mean_invstd, scale_shift, pool):
-    """-> (dx like x, dweight [C] fp32, dbias [C] fp32)."""
+def conv_tail_backward(x, dy, mean_invstd, scale_shift, pool, residual=None):
+    """-> (dx like x, dweight [C] fp32, dbias [C] fp32[, dresidual like x when ``residual`` is given])."""
     rows, c = _tail_view(x)
     if dy.dtype != x.dtype or not dy.is_contiguous(memory_format=torch.channels_last):
         dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
     index = ensure_init(x.device)
     dx = torch.empty_like(x, memory_format=torch.channels_last)
+    dres = torch.empty_like(x, memory_format=torch.channels_last) if residual is not None else None
     dwb = torch.empty((2, c), dtype=torch.float32, device=x.device)
     lib = load_library()
     ws = torch.empty(lib.seld_conv_tail_workspace_floats(c), dtype=torch.float32, device=x.device)
     with torch.cuda.device(index):
-        check(lib.seld_conv_tail_backward(_p(x), _p(dy), int(x.dtype == torch.bfloat16), rows, c, pool, _p(mean_invstd),
-                                          _p(scale_shift), _p(dx), _p(dwb[0]), _p(dwb[1]), _p(ws),
-                                          _stream_ptr(x.device)), "seld_conv_tail_backward")
+        check(lib.seld_conv_tail_backward(_p(x), _p(residual), _p(dy), int(x.dtype == torch.bfloat16), rows, c, pool,
+                                          _p(mean_invstd), _p(scale_shift), _p(dx), _p(dres), _p(dwb[0]), _p(dwb[1]),
+                                          _p(ws), _stream_ptr(x.device)), "seld_conv_tail_backward")
+    if residual is not None:
+        return dx, dwb[0], dwb[1], dres
     return dx, dwb[0], dwb[1]
 
 

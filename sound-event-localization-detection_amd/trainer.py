@@ -54,9 +54,10 @@ config = Config()
 # model factory (trainer.py:50-95 / :432-473)
 # ------------------------------------------------------------------------------------------------
 
-def build_model(grid_size, use_small_model=True, model_type=None):
+def build_model(grid_size, use_small_model=True, model_type=None, n_channels=None):
     kind = config.MODEL_TYPE if model_type is None else model_type
-    common = dict(n_channels=config.N_CHANNELS, grid_size=grid_size, num_classes=config.NUM_CLASSES)
+    common = dict(n_channels=config.N_CHANNELS if n_channels is None else n_channels, grid_size=grid_size,
+                  num_classes=config.NUM_CLASSES)
     if kind == "crnn":
         logger.info("Initializing CRNN model...")
         return SELD_CRNN(n_mels=config.N_MELS, cnn_channels=config.CRNN_CNN_CHANNELS,
@@ -285,7 +286,9 @@ def train_model(train_loader, test_loader, num_epochs=None, batch_size=None, lea
     logger.info(f"Test dataset: {len(test_dataset)} windows ({len(test_loader)} batches)")
     logger.info(f"Grid dimensions: {grid[0]}x{grid[1]} = {train_dataset.total_cells} cells; world size {world}")
 
-    model = prepare_model_for_device(build_model(grid, use_small_model), device)
+    # input channels follow the dataset's feature set (4 log-mel; 7 with intensity vectors; 36 for 8-ch GCC-PHAT)
+    n_channels = getattr(train_loader.dataset, "n_channels", None)
+    model = prepare_model_for_device(build_model(grid, use_small_model, n_channels=n_channels), device)
     n_params = sum(p.numel() for p in model.parameters())
     model = wrap_ddp(model, device, world)
 
@@ -450,7 +453,8 @@ def test_model(test_loader, model_path=None, batch_size=None, device=None, num_v
         return {}
 
     checkpoint = safe_torch_load(model_path, map_location=device)
-    model = prepare_model_for_device(build_model(grid, True), device)
+    model = prepare_model_for_device(build_model(grid, True, n_channels=getattr(test_dataset, "n_channels", None)),
+                                     device)
     model.load_state_dict(checkpoint["model_state_dict"])
     model.eval()
     logger.info(f"Model loaded (epoch {checkpoint['epoch']}, test loss {checkpoint['test_loss']:.6f})")

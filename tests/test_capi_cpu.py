@@ -128,3 +128,32 @@ def test_lane_emulator_layouts_int16_and_floor(emu_lib):
     xi = ofeat.pcm_to_int16(pcm)
     assert_logmel_close(_emu(emu_lib, xi), ofeat.logmel_torch(ofeat.int16_to_pcm(xi)).numpy())
     assert (_emu(emu_lib, torch.zeros(1, 5000)) == -100.0).all()
+
+
+def test_device_code_has_no_vcc_scc_select_miscompile(tmp_path):
+    """hipcc (ROCm 7.2, gfx950) lowered a uniform 64-bit ``min(n - cell0, 256)`` in two instantiations of the loss
+    kernel to ``v_cmp_lt_i64 vcc`` + ``s_cselect_b32`` WITHOUT copying VCC to SCC: the select then read the stale
+    carry of the preceding subtraction and the ragged last tile was processed as a full one.  The source now uses
+    32-bit extents there; this scans the ISA of every kernel file for the pattern so a re-appearance is caught on
+    the CPU."""
+    import re
+    import subprocess
+    from pathlib import Path
+    csrc = Path(__file__).resolve().parent.parent / "sound-event-localization-detection_amd" / "csrc"
+    scc_writer = re.compile(r"^\s*(s_cmp|s_and_|s_or_|s_xor_|s_andn2|s_orn2|s_bitcmp|s_add|s_sub|s_addc|s_subb|s_lshl|s_lshr|"
+                            r"s_ashr|s_min|s_max|s_abs|s_not|s_bcnt|s_absdiff|s_nand|s_nor|s_xnor|s_bfe)")
+    for src in sorted(csrc.glob("*.hip")):
+        out = tmp_path / (src.stem + ".s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", f"-I{csrc.parent.parent / 'include'}",
+                        "-S", "--cuda-device-only", str(src), "-o", str(out)], check=True, capture_output=True)
+        lines = out.read_text().splitlines()
+        for i, line in enumerate(lines):
+            if "s_cselect" not in line:
+                continue
+            j = i - 1
+            while j >= 0 and not scc_writer.match(lines[j]) and "s_cselect" not in lines[j] and not lines[j].strip().endswith(":"):
+                j -= 1
+            writer = lines[j].strip() if j >= 0 else ""
+            wide_cmp = [x for x in lines[j + 1:i] if "v_cmp" in x and "64" in x]
+            assert not (wide_cmp and writer.startswith(("s_sub", "s_add", "s_lsh"))), \
+                f"{src.name}: '{line.strip()}' selects on the SCC of '{writer}' after '{wide_cmp[0].strip()}'"

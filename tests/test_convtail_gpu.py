@@ -160,3 +160,67 @@ def test_rejects_unsupported_layouts(gpu_device):
         seld_native.conv_tail_forward(x, None, None, None, None, 0.1, 1e-5, True, 2)
     assert not seld_native.conv_tail_supported(12) and not seld_native.conv_tail_supported(8 * 3)
     assert seld_native.conv_tail_supported(64) and seld_native.conv_tail_supported(512)
+
+
+@pytest.mark.parametrize("shape,dtype", [((2, 64, 5, 8), torch.float32), ((3, 256, 50, 16), torch.float32),
+                                         ((8, 256, 250, 16), torch.bfloat16)])
+def test_residual_mode_matches_bottleneck_tail(gpu_device, shape, dtype):
+    """relu(bn3(y) + shortcut) of a ResNet bottleneck (resnet50_model.py:30-52): forward, dx, d(shortcut), dW, db."""
+    import seld_native
+    c = shape[1]
+    bn = nn.BatchNorm2d(c).to(gpu_device)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, device=gpu_device) + 0.5)
+        bn.bias.copy_(torch.randn(c, device=gpu_device) * 0.3)
+    x = _inputs(shape, gpu_device, 21).to(dtype).contiguous(memory_format=torch.channels_last)
+    res = _inputs(shape, gpu_device, 22).to(dtype).contiguous(memory_format=torch.channels_last)
+    x32, r32 = x.float().requires_grad_(True), res.float().requires_grad_(True)
+    y_ref = torch.relu(bn(x32) + r32)
+    go = torch.randn_like(y_ref).to(dtype)
+    y_ref.backward(go.float())
+    rm, rv = torch.zeros(c, device=gpu_device), torch.ones(c, device=gpu_device)
+    y, mi, ss = seld_native.conv_tail_forward(x, bn.weight.detach(), bn.bias.detach(), rm, rv, 0.1, bn.eps, True, 1,
+                                              residual=res)
+    dx, dw, db, dres = seld_native.conv_tail_backward(x, go.contiguous(memory_format=torch.channels_last), mi, ss, 1,
+                                                      residual=res)
+    if dtype == torch.float32:
+        assert _mostly_close(y, y_ref, 2e-5)
+        assert _mostly_close(dx, x32.grad, 1e-4) and _mostly_close(dres, r32.grad, 1e-6)
+        tol = 2e-4
+    else:
+        assert ((y.float() - y_ref).abs() <= y_ref.abs() * 2 ** -6 + 2e-2).float().mean().item() >= 0.9999
+        # bf16: an element whose rounded pre-activation lands on the other side of zero routes differently from the
+        # fp32 reference; the aggregate error is what is bounded (the unfused bf16 modules behave the same way)
+        assert (dx.float() - x32.grad).norm().item() <= 5e-2 * x32.grad.norm().item()
+        assert (dres.float() - r32.grad).norm().item() <= 5e-2 * r32.grad.norm().item()
+        tol = 2e-2
+    for got, want, name in ((dw, bn.weight.grad, "dweight"), (db, bn.bias.grad, "dbias")):
+        assert (got - want).abs().max().item() <= tol * (want.abs().max().item() + 1e-6), name
+
+
+def test_resnet_bottleneck_uses_fused_tails(gpu_device):
+    import seld_convtail
+    from resnet50_model import Bottleneck
+    torch.manual_seed(5)
+    down = nn.Sequential(nn.Conv2d(64, 256, 1, bias=False), nn.BatchNorm2d(256))
+    blk = Bottleneck(64, 64, 1, down).to(gpu_device).to(memory_format=torch.channels_last)
+    ref = Bottleneck(64, 64, 1, nn.Sequential(nn.Conv2d(64, 256, 1, bias=False), nn.BatchNorm2d(256)))
+    ref = ref.to(gpu_device).to(memory_format=torch.channels_last)
+    ref.load_state_dict(blk.state_dict())
+    x = torch.randn(2, 64, 10, 8, device=gpu_device).contiguous(memory_format=torch.channels_last)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    y = blk(xa)
+    seld_convtail.enabled = False
+    try:
+        y_ref = ref(xb)
+    finally:
+        seld_convtail.enabled = True
+    assert (y - y_ref).abs().max().item() <= 1e-4 * y_ref.abs().max().item()
+    go = torch.randn_like(y)
+    y.backward(go)
+    y_ref.backward(go)
+    assert (xa.grad - xb.grad).abs().max().item() <= 5e-4 * xb.grad.abs().max().item()
+    for (n, p), (_, q) in zip(blk.named_parameters(), ref.named_parameters()):
+        assert (p.grad - q.grad).abs().max().item() <= 5e-4 * (q.grad.abs().max().item() + 1e-6), n
+    for (n, p), (_, q) in zip(blk.named_buffers(), ref.named_buffers()):
+        assert torch.allclose(p.float(), q.float(), rtol=1e-4, atol=1e-5), n

@@ -134,3 +134,49 @@ def test_main_py_call_sequence(gpu_device, clips, tmp_path):
     cfg.DEVICE_FEED = True
     # both batch sources train the same model on the same windows (different shuffles / bf16 noise): same ballpark
     assert abs(losses[True][-1] - losses[False][-1]) <= 0.2 * max(losses[True][-1], losses[False][-1])
+
+
+def test_mic_array_gcc_feature_set_end_to_end(gpu_device, tmp_path):
+    """BASELINE configs[3] in miniature: 8-channel MIC recordings, FEATURE_SET = 'logmel_gcc' (8 log-mel + 28 GCC-PHAT
+    channels, csrc/spatial.hip), a CRNN whose input width follows the dataset, one training epoch + evaluation.
+    The first 8 feature channels are the reference's per-channel log-mel (dataset.py:27-58): checked against the
+    oracle; the GCC-PHAT channels have no upstream counterpart (self-oracle: tests/test_spatial_gpu.py)."""
+    import dataset
+    import trainer
+    cfg = trainer.config
+    saved = (cfg.FEATURE_SET, cfg.MODEL_TYPE, cfg.CRNN_CNN_CHANNELS, cfg.CRNN_RNN_HIDDEN, cfg.NUM_EPOCHS, cfg.BATCH_SIZE,
+             cfg.OUTPUT_PATH, cfg.CHECKPOINT_PATH)
+    try:
+        cfg.FEATURE_SET, cfg.MODEL_TYPE, cfg.CRNN_CNN_CHANNELS, cfg.CRNN_RNN_HIDDEN = "logmel_gcc", "crnn", [8, 8, 16, 16], 16
+        cfg.NUM_EPOCHS, cfg.BATCH_SIZE, cfg.SEED = 1, 4, 0
+        cfg.OUTPUT_PATH, cfg.CHECKPOINT_PATH = tmp_path / "outputs", tmp_path / "checkpoints"
+        cfg.OUTPUT_PATH.mkdir()
+        cfg.CHECKPOINT_PATH.mkdir()
+        files = []
+        for idx, n in enumerate((24000 * 6 + 100, 24000 * 5)):
+            pcm = ofeat.pcm_to_int16(ofeat.synth_pcm(20 + idx, 8, n, "noise")).numpy()
+            wav, csv_path = tmp_path / f"mic{idx}.wav", tmp_path / f"mic{idx}.csv"
+            with wave.open(str(wav), "wb") as wf:
+                wf.setnchannels(8)
+                wf.setsampwidth(2)
+                wf.setframerate(24000)
+                wf.writeframes(np.ascontiguousarray(pcm.T).tobytes())
+            csv_path.write_text(olab.metadata_to_csv(olab.synth_metadata(20 + idx, meta_frames=50)))
+            files.append((str(wav), str(csv_path), pcm))
+        ds = dataset.SELDDataset([f[0] for f in files], [f[1] for f in files], num_classes=cfg.NUM_CLASSES)
+        assert ds.n_channels == 8 + 28
+        spec, labels = ds[0]
+        assert tuple(spec.shape) == (250, 36, 64) and tuple(labels.shape) == (250, 648, 14)
+        ref = ofeat.logmel_torch(ofeat.int16_to_pcm(torch.from_numpy(files[0][2])))            # [8, 64, F]
+        assert_logmel_close(spec[:, :8].permute(1, 2, 0), ref[:, :, :250])
+        assert torch.isfinite(spec).all()
+        loader = DataLoader(ds, batch_size=cfg.BATCH_SIZE, shuffle=True)
+        model, history = trainer.train_model(train_loader=loader, test_loader=loader, device=torch.device("cuda"))
+        assert trainer.unwrap(model).cnn_blocks[0].conv.in_channels == 36
+        assert history["total_epochs"] == 1 and np.isfinite(history["best_test_loss"])
+        results = trainer.test_model(test_loader=loader, model_path=cfg.CHECKPOINT_PATH / "best_model.pth",
+                                     device=torch.device("cuda"), num_visualizations=1, save_visualizations=False)
+        assert np.isfinite(results["test_loss"])
+    finally:
+        (cfg.FEATURE_SET, cfg.MODEL_TYPE, cfg.CRNN_CNN_CHANNELS, cfg.CRNN_RNN_HIDDEN, cfg.NUM_EPOCHS, cfg.BATCH_SIZE,
+         cfg.OUTPUT_PATH, cfg.CHECKPOINT_PATH) = saved

@@ -84,3 +84,27 @@ def test_module_backward_with_and_without_upstream_scale(gpu_device, dtype):
         ref.backward()
         tol = 1e-4 if dtype == torch.float32 else 1e-2
         assert (a.grad.float() - b.grad).abs().max().item() <= tol * b.grad.abs().max().item(), factor
+
+
+@pytest.mark.parametrize("n_cells", [1, 257, 2048 * 256 + 1, 324000, 648000])
+def test_every_variant_at_ragged_sizes(gpu_device, n_cells):
+    """All eight instantiations (bf16 / fp32 logits x mask / dense labels x value-only / value + gradient) on sizes
+    whose last tile is ragged, against plain torch.  Regression test for a hipcc miscompile (64-bit min() of the
+    tile extent lowered to v_cmp + s_cselect without the VCC->SCC copy) that made the value-only bf16 kernels --
+    the ones evaluation uses -- treat the ragged tile as a full one."""
+    import seld_native
+    import loss as loss_mod
+    g = torch.Generator().manual_seed(n_cells)
+    logits = (torch.randn(n_cells, 14, generator=g) * 2).to(gpu_device)
+    mask = ((torch.rand(n_cells, generator=g) < 0.05).to(torch.int32) * (1 << 3)).to(torch.uint16).to(gpu_device)
+    dense = loss_mod.mask_to_dense(mask, 14)
+    # poison whatever lies behind the tensors: an over-read must show
+    for dtype in (torch.bfloat16, torch.float32):
+        lg = logits.to(dtype)
+        ref = torch.nn.functional.mse_loss(torch.softmax(lg.float(), -1), dense).item()
+        for labels in (mask, dense):
+            value, none = seld_native.softmax_mse(lg, labels)
+            value2, grad = seld_native.softmax_mse(lg, labels, grad_scale=1.0)
+            assert none is None and grad.shape == lg.shape
+            assert abs(value.item() - ref) <= 1e-5 * ref, (dtype, labels.dtype, value.item(), ref)
+            assert abs(value2.item() - ref) <= 1e-5 * ref, (dtype, labels.dtype, value2.item(), ref)
