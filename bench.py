@@ -22,9 +22,16 @@ The JSON line also carries
   roofline      : the hand-written log-mel kernel against the HBM roofline -- algorithmic bytes
                   (26.11 MB per 60 s clip: 23.04 MB fp32 PCM in + 3.07 MB log-mel out) x 32
                   clips per launch / average launch duration measured with HIP events on the launch stream;
-  roofline_model: the CRNN fwd+bwd iterations against the dense bf16 MFMA peak (39.4 GFLOP/window);
+                  `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/);
+  roofline_model: the optimiser iterations against the dense bf16 MFMA peak (39.4 GFLOP/window for the CRNN);
+  kernels       : every other hand-written kernel (conv tail, loss, window gather, BiGRU recurrence) at the
+                  workload's shapes against the roofline that bounds it, timed after the timed region;
   cpu_baseline  : the oracle (torch CPU restatement of the reference path) timed on this host's
                   cores on a bounded sample -- a reported, non-target number.
+
+Other workloads (parity / coverage cases of BASELINE.json, not the headline): --model conformer | resnet_conformer;
+--features logmel_gcc --channels 8 (configs[3]'s per-GPU shard: 8-ch MIC array, 36 input channels);
+SELD_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the DDP path (never a measurement).
 """
 from __future__ import annotations
 

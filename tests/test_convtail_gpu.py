@@ -193,7 +193,9 @@ def test_residual_mode_matches_bottleneck_tail(gpu_device, shape, dtype):
         # fp32 reference; the aggregate error is what is bounded (the unfused bf16 modules behave the same way)
         assert (dx.float() - x32.grad).norm().item() <= 5e-2 * x32.grad.norm().item()
         assert (dres.float() - r32.grad).norm().item() <= 5e-2 * r32.grad.norm().item()
-        tol = 2e-2
+        for got, want, name in ((dw, bn.weight.grad, "dweight"), (db, bn.bias.grad, "dbias")):
+            assert (got - want).norm().item() <= 5e-2 * want.norm().item(), name
+        return
     for got, want, name in ((dw, bn.weight.grad, "dweight"), (db, bn.bias.grad, "dbias")):
         assert (got - want).abs().max().item() <= tol * (want.abs().max().item() + 1e-6), name
 

@@ -147,6 +147,8 @@ def test_mic_array_gcc_feature_set_end_to_end(gpu_device, tmp_path):
     saved = (cfg.FEATURE_SET, cfg.MODEL_TYPE, cfg.CRNN_CNN_CHANNELS, cfg.CRNN_RNN_HIDDEN, cfg.NUM_EPOCHS, cfg.BATCH_SIZE,
              cfg.OUTPUT_PATH, cfg.CHECKPOINT_PATH)
     try:
+        # config.py is edited in place upstream (class attributes); dataset.py and trainer.py each hold an instance
+        type(cfg).FEATURE_SET = "logmel_gcc"
         cfg.FEATURE_SET, cfg.MODEL_TYPE, cfg.CRNN_CNN_CHANNELS, cfg.CRNN_RNN_HIDDEN = "logmel_gcc", "crnn", [8, 8, 16, 16], 16
         cfg.NUM_EPOCHS, cfg.BATCH_SIZE, cfg.SEED = 1, 4, 0
         cfg.OUTPUT_PATH, cfg.CHECKPOINT_PATH = tmp_path / "outputs", tmp_path / "checkpoints"
@@ -178,5 +180,6 @@ def test_mic_array_gcc_feature_set_end_to_end(gpu_device, tmp_path):
                                      device=torch.device("cuda"), num_visualizations=1, save_visualizations=False)
         assert np.isfinite(results["test_loss"])
     finally:
+        type(cfg).FEATURE_SET = "logmel"
         (cfg.FEATURE_SET, cfg.MODEL_TYPE, cfg.CRNN_CNN_CHANNELS, cfg.CRNN_RNN_HIDDEN, cfg.NUM_EPOCHS, cfg.BATCH_SIZE,
          cfg.OUTPUT_PATH, cfg.CHECKPOINT_PATH) = saved
