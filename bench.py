@@ -123,6 +123,7 @@ class HotPath:
         extra = {"logmel": 0, "logmel_iv": 3, "logmel_gcc": args.channels * (args.channels - 1) // 2}[args.features]
         self.feature_channels = args.channels + extra
         model = trainer.prepare_model_for_device(trainer.build_model((18, 36), n_channels=self.feature_channels), device)
+        trainer.enable_master_weights(model, device)
         self.model = trainer.wrap_ddp(model, device, world)
         weights = torch.ones(14, device=device)
         weights[13] = 0.05
@@ -375,6 +376,9 @@ def main():
                                "bound": "mfma", "achieved": model_tflops, "peak": MFMA_BF16_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": model_tflops / MFMA_BF16_PEAK_TFLOPS, "avg_ms": model_ms},
         }
+        if hasattr(hot.optimizer, "fused_casts"):
+            line["config"]["master_weights"] = {"one_launch_gradient_casts": hot.optimizer.fused_casts,
+                                                "per_tensor_fallbacks": hot.optimizer.fallback_casts}
         if world == 1:
             line["kernels"] = kernel_rooflines(device)
         if world == 1 and not args.no_cpu_baseline:

@@ -130,6 +130,14 @@ int seld_softmax_mse(const void* logits, int logits_is_bf16, const uint16_t* mas
  * touched.  n must be a multiple of 8; data bf16 when is_bf16, else fp32, 16-byte aligned. */
 int seld_scale_by_device_scalar(void* data, int is_bf16, int64_t n, const float* scale, void* stream);
 
+/* One launch per 96 tensors casts a list of tensors (the fp32-master / bf16-working-weight mode of the trainer):
+ * src / dst are HOST arrays of `count` device addresses, lengths a HOST array of element counts (the descriptors are
+ * passed to the kernel by value).  bf16_to_fp32 != 0: bf16 sources -> fp32 destinations (gradients); 0: fp32 -> bf16
+ * (weights), round to nearest even.  Source and destination of a pair must share their memory layout (the cast walks
+ * the storage).  No reference counterpart: replaces the per-parameter casts of torch.autocast. */
+int seld_multi_cast(const void* const* src, void* const* dst, const int64_t* lengths, int count, int bf16_to_fp32,
+                    void* stream);
+
 /* ---- CNN block tail: BatchNorm2d -> ReLU -> MaxPool2d((1,2)) at model_crnn.py:5-17 (ConvBlock.forward) ---- */
 /* x: the convolution output in channels-last memory order = row-major [rows = B*T*F][C] (bf16 when is_bf16, else
  * fp32); the two frequency bins of a pooling pair are adjacent rows.  pool = 2: MaxPool2d((1,2)); pool = 1: no

@@ -93,6 +93,9 @@ class Config:
     FUSED_CONV_TAIL = True      # BatchNorm -> ReLU -> MaxPool of the CNN blocks in two HBM passes (csrc/convtail.hip)
     FUSED_GRU = True            # persistent BiGRU kernel instead of MIOpen's per-step GEMMs
     DEVICE_FEED = True          # train from device-resident features / compact labels (no 290 MB/step H2D)
+    MASTER_WEIGHTS = True       # bf16 runs: the conv / Linear / GRU weight matrices live in the model as bf16 working
+                                # copies of fp32 masters owned by the optimiser (same values autocast would cast to
+                                # every iteration, without ~40-340 cast kernels per iteration; bf16 gradient all-reduce)
     DDP_BUCKET_MB = 25          # RCCL all-reduce bucket size
     SYNC_BATCHNORM = False      # per-rank BN statistics by default
     SEED = None                 # the reference never seeds; set an int for reproducible runs

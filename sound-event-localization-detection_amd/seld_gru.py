@@ -43,6 +43,7 @@ class _BiGRULayer(torch.autograd.Function):
             y, saved = seld_native.gru_forward(gi.view(b, t, 2, 3 * HIDDEN), w_hh, b_hh[:, 2 * HIDDEN:], need)
         ctx.save_for_backward(xc, w_ih, w_hh, y, saved if saved is not None else torch.empty(0))
         ctx.cdt = cdt
+        ctx.dtypes = (w_ih.dtype, b_ih.dtype, w_hh.dtype, b_hh.dtype)
         return y
 
     @staticmethod
@@ -75,8 +76,9 @@ class _BiGRULayer(torch.autograd.Function):
             p_n = tall_product(dghn.view(n, 2 * h), hp).view(2, h, 2, h)
             dw_hh = torch.stack([torch.cat((p_gi[d, :2, :, d].reshape(2 * h, h), p_n[d, :, d]), dim=0)
                                  for d in range(2)], dim=0)
+        t_wih, t_bih, t_whh, t_bhh = ctx.dtypes
         return dx.to(dy.dtype) if dx.dtype != dy.dtype and not torch.is_autocast_enabled() else dx, \
-            dw_ih.to(w_ih.dtype), db_ih.to(w_ih.dtype), dw_hh.to(w_hh.dtype), db_hh.to(w_hh.dtype)
+            dw_ih.to(t_wih), db_ih.to(t_bih), dw_hh.to(t_whh), db_hh.to(t_bhh)
 
 
 class _Joined(torch.autograd.Function):

@@ -39,6 +39,8 @@ class _Linear(torch.autograd.Function):
         ctx.save_for_backward(xc, wc)
         ctx.has_bias = bias is not None
         ctx.in_dtype = x.dtype
+        ctx.w_dtype = weight.dtype
+        ctx.b_dtype = bias.dtype if bias is not None else None
         return y
 
     @staticmethod
@@ -52,6 +54,10 @@ class _Linear(torch.autograd.Function):
             db = torch.sum(g2, dim=0, dtype=torch.float32) if ctx.has_bias and ctx.needs_input_grad[2] else None
         if dx is not None and dx.dtype != ctx.in_dtype:
             dx = dx.to(ctx.in_dtype)
+        if dw is not None and dw.dtype != ctx.w_dtype:          # bf16 working weights (trainer.MasterWeightAdam)
+            dw = dw.to(ctx.w_dtype)
+        if db is not None and db.dtype != ctx.b_dtype:
+            db = db.to(ctx.b_dtype)
         return dx, dw, db
 
 

@@ -64,6 +64,7 @@ def _declare(lib):
     lib.seld_softmax_mse_workspace_bytes.argtypes = []
     lib.seld_softmax_mse.argtypes = [_ptr, _int, _ptr, _ptr, _i64, _int, ctypes.c_float, _ptr, _ptr, _ptr, _ptr]
     lib.seld_scale_by_device_scalar.argtypes = [_ptr, _int, _i64, _ptr, _ptr]
+    lib.seld_multi_cast.argtypes = [_ptr, _ptr, _ptr, _int, _int, _ptr]
     lib.seld_conv_tail_workspace_floats.restype = _i64
     lib.seld_conv_tail_workspace_floats.argtypes = [_int]
     lib.seld_conv_tail_forward.argtypes = [_ptr, _ptr, _int, _i64, _int, _int, _ptr, _ptr, _ptr, _ptr, ctypes.c_float,
@@ -340,6 +341,37 @@ def scale_by_device_scalar_(data: torch.Tensor, scale: torch.Tensor) -> torch.Te
                                                          _p(scale), _stream_ptr(data.device)),
               "seld_scale_by_device_scalar")
     return data
+
+
+def _dense_like(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """Same shape and strides, and the storage is walked exactly once (contiguous in some memory format)."""
+    if a.shape != b.shape or a.device != b.device:
+        return False
+    if any(sa != sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1):     # size-1 dims: any stride
+        return False
+    return a.is_contiguous() or (a.dim() == 4 and a.is_contiguous(memory_format=torch.channels_last))
+
+
+def multi_cast(srcs, dsts) -> bool:
+    """dsts[i] <- srcs[i] for lists of GPU tensors, bf16 -> fp32 or fp32 -> bf16 (all pairs the same direction), in one
+    launch per 96 tensors (csrc/cast.hip).  Returns False -- having done nothing -- when a pair does not share its
+    memory layout, so that the caller can fall back to the framework's copies."""
+    srcs, dsts = list(srcs), list(dsts)
+    if not srcs:
+        return True
+    to_float = srcs[0].dtype == torch.bfloat16
+    want = (torch.bfloat16, torch.float32) if to_float else (torch.float32, torch.bfloat16)
+    for s, d in zip(srcs, dsts):
+        if s.dtype != want[0] or d.dtype != want[1] or not s.is_cuda or not _dense_like(s, d):
+            return False
+    n = len(srcs)
+    src = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
+    dst = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts])
+    lengths = (ctypes.c_int64 * n)(*[s.numel() for s in srcs])
+    device = srcs[0].device
+    with torch.cuda.device(ensure_init(device)):
+        check(load_library().seld_multi_cast(src, dst, lengths, n, int(to_float), _stream_ptr(device)), "seld_multi_cast")
+    return True
 
 
 # --------------------------------------------------------------------------- CNN block tail (BN + ReLU + pool)

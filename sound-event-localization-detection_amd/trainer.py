@@ -245,16 +245,114 @@ def eval_step(model, criterion, spectrograms, labels, device):
     return predictions, total.detach(), term.detach()
 
 
+# ------------------------------------------------------------------------------------------------
+# fp32 master weights behind bf16 working copies
+# ------------------------------------------------------------------------------------------------
+# Under autocast every conv / Linear / GRU weight is cast fp32 -> bf16 once per iteration and every weight gradient
+# bf16 -> fp32: one tiny kernel each (36 per CRNN iteration, 336 per ResNet50-Conformer iteration, ~5 us apiece on an
+# otherwise GPU-bound step).  With MASTER_WEIGHTS the model holds the bf16 values themselves -- bit-identical to what
+# autocast would produce from the fp32 masters -- and the optimiser owns the fp32 masters: per iteration ONE
+# multi-tensor copy of the bf16 gradients into the masters' fp32 gradients, fused Adam on the masters, ONE
+# multi-tensor copy back.  Under DDP the weight gradients are then all-reduced in bf16 (half the xGMI bytes).
+# BatchNorm / LayerNorm parameters and all biases stay fp32 (autocast keeps those ops in fp32 as well).
+
+def enable_master_weights(model, device):
+    """Convert in place; returns True when active.  Call before wrap_ddp / make_optimizer."""
+    if not (device.type == "cuda" and getattr(config, "MASTER_WEIGHTS", True)
+            and getattr(config, "AMP_DTYPE", "bf16") == "bf16"):
+        return False
+    import seld_gru
+    target = unwrap(model)
+    low, masters, names = [], [], {}
+    for mod_name, module in target.named_modules():
+        if not isinstance(module, (torch.nn.Conv1d, torch.nn.Conv2d, torch.nn.Linear, torch.nn.GRU)):
+            continue
+        for pname, p in module.named_parameters(recurse=False):
+            if p.ndim >= 2 and p.dtype == torch.float32 and p.requires_grad:
+                master = p.detach().clone()
+                p.data = p.data.to(torch.bfloat16)
+                low.append(p)
+                masters.append(master)
+                names[f"{mod_name}.{pname}" if mod_name else pname] = master
+        if isinstance(module, SeldGRU) and SeldGRU.fused_enabled:
+            seld_gru.pack_parameters(module)          # keep (forward, reverse) pairs adjacent in their new dtype
+    target._seld_master_weights = (low, masters, names)
+    return True
+
+
+def disable_master_weights(model):
+    """Give the model its fp32 weights back (what ``train_model`` returns and what checkpoints hold)."""
+    target = unwrap(model)
+    state = getattr(target, "_seld_master_weights", None)
+    if state is None:
+        return
+    for p, master in zip(state[0], state[1]):
+        p.data = master.detach().clone()
+        p.grad = None
+    del target._seld_master_weights
+
+
+def model_state_dict(model):
+    """``state_dict`` with the fp32 masters in place of the bf16 working copies (checkpoint format unchanged)."""
+    target = unwrap(model)
+    sd = target.state_dict()
+    state = getattr(target, "_seld_master_weights", None)
+    if state is not None:
+        for name, master in state[2].items():
+            sd[name] = master.detach().clone()
+    return sd
+
+
+class MasterWeightAdam(torch.optim.Adam):
+    """Adam over (fp32 masters of the bf16 working weights) + (the remaining fp32 parameters)."""
+
+    def __init__(self, low, masters, others, **kwargs):
+        super().__init__(list(masters) + list(others), **kwargs)
+        self._low, self._masters, self._others = list(low), list(masters), list(others)
+        self.fused_casts = self.fallback_casts = 0        # how often the one-launch casts applied (diagnostics)
+        for m in self._masters:
+            m.grad = torch.zeros_like(m)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        import seld_native
+        grads = [p.grad for p in self._low]
+        master_grads = [m.grad for m in self._masters]
+        if all(g is not None for g in grads) and seld_native.multi_cast(grads, master_grads):
+            self.fused_casts += 1
+        else:
+            self.fallback_casts += 1
+            for m, g in zip(self._masters, grads):       # a parameter without a gradient, or a layout mismatch
+                m.grad.zero_() if g is None else m.grad.copy_(g)
+        out = super().step(closure)
+        working = [p.data for p in self._low]
+        if not seld_native.multi_cast(self._masters, working):
+            torch._foreach_copy_(working, self._masters)
+        return out
+
+    def zero_grad(self, set_to_none=True):
+        for p in self._low + self._others:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+
 def make_optimizer(model, learning_rate, device):
     kwargs = dict(lr=learning_rate, weight_decay=config.WEIGHT_DECAY)
     if device.type == "cuda":
         kwargs["fused"] = True            # one multi-tensor kernel instead of ~4 launches per parameter
+    state = getattr(unwrap(model), "_seld_master_weights", None)
+    if state is not None:
+        low_ids = {id(p) for p in state[0]}
+        others = [p for p in model.parameters() if id(p) not in low_ids]
+        return MasterWeightAdam(state[0], state[1], others, **kwargs)
     return torch.optim.Adam(model.parameters(), **kwargs)
 
 
 def checkpoint_payload(epoch, model, optimizer, train_loss, test_loss):
     """The dict format of trainer.py:278-285 (the Config INSTANCE is pickled, as upstream)."""
-    return {"epoch": epoch, "model_state_dict": unwrap(model).state_dict(),
+    return {"epoch": epoch, "model_state_dict": model_state_dict(model),
             "optimizer_state_dict": optimizer.state_dict(), "train_loss": train_loss, "test_loss": test_loss,
             "config": config}
 
@@ -290,6 +388,7 @@ def train_model(train_loader, test_loader, num_epochs=None, batch_size=None, lea
     n_channels = getattr(train_loader.dataset, "n_channels", None)
     model = prepare_model_for_device(build_model(grid, use_small_model, n_channels=n_channels), device)
     n_params = sum(p.numel() for p in model.parameters())
+    enable_master_weights(model, device)
     model = wrap_ddp(model, device, world)
 
     class_weights = torch.ones(config.NUM_CLASSES, device=device)
@@ -408,6 +507,7 @@ def train_model(train_loader, test_loader, num_epochs=None, batch_size=None, lea
         plot_loss_curves(train_losses, test_losses, save_path=config.OUTPUT_PATH / f"loss_curves_{stamp}.png")
     if world > 1:
         dist.barrier()
+    disable_master_weights(model)                 # the returned model holds plain fp32 parameters again
     best_path = config.CHECKPOINT_PATH / "best_model.pth"
     if best_path.exists():
         best = safe_torch_load(best_path, map_location=device)

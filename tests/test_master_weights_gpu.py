@@ -1,0 +1,72 @@
+"""GPU test of the fp32-master / bf16-working-weight training mode (trainer.MasterWeightAdam): same numbers as the
+autocast path it replaces (the bf16 working copies ARE the values autocast casts to every iteration), checkpoints
+keep fp32 parameters under the reference's keys, and the model handed back is plain fp32."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(master, device, steps=6):
+    import trainer
+    cfg = trainer.config
+    saved = (cfg.MASTER_WEIGHTS, cfg.MODEL_TYPE, cfg.CRNN_CNN_CHANNELS)
+    cfg.MASTER_WEIGHTS, cfg.MODEL_TYPE, cfg.CRNN_CNN_CHANNELS = master, "crnn", [16, 16, 32, 32]
+    try:
+        torch.manual_seed(0)
+        model = trainer.prepare_model_for_device(trainer.build_model((18, 36)), device).train()
+        active = trainer.enable_master_weights(model, device)
+        assert active == master
+        crit = trainer.SMRSELDLoss("mse", 1.0, grid_size=(18, 36))
+        opt = trainer.make_optimizer(model, 1e-3, device)
+        g = torch.Generator().manual_seed(1)
+        x = (torch.randn(8, 250, 4, 64, generator=g) * 20 - 30).to(device)
+        mask = (torch.rand(8, 250, 648, generator=g) < 0.01).to(torch.int32).mul(1 << 4).to(torch.uint16).to(device)
+        losses = []
+        for _ in range(steps):
+            total, _ = trainer.train_step(model, crit, opt, x, mask, device)
+            losses.append(total.item())
+        sd = trainer.model_state_dict(model)
+        trainer.disable_master_weights(model)
+        return losses, sd, model
+    finally:
+        cfg.MASTER_WEIGHTS, cfg.MODEL_TYPE, cfg.CRNN_CNN_CHANNELS = saved
+
+
+def test_master_weights_track_the_autocast_path(gpu_device):
+    from seld_rnn import SeldGRU
+    la, sda, ma = _run(False, gpu_device)
+    lb, sdb, mb = _run(True, gpu_device)
+    assert np.allclose(la, lb, rtol=2e-3), (la, lb)             # same arithmetic, different kernel order / rounding
+    assert la[-1] < la[0] and lb[-1] < lb[0]
+    assert list(sda.keys()) == list(sdb.keys())
+    for k in sda:
+        assert sdb[k].dtype == sda[k].dtype, k                   # checkpoints hold fp32 parameters
+        if sda[k].dtype == torch.float32 and sda[k].numel() > 1:
+            # six Adam steps move every parameter by at most ~6 * lr; the two runs may disagree on the sign of a
+            # near-zero gradient component, so compare on that scale
+            assert (sda[k] - sdb[k]).abs().max().item() <= 4e-3 + 1e-2 * sda[k].abs().max().item(), k
+    assert all(p.dtype == torch.float32 for p in mb.parameters())   # handed back as a plain fp32 model
+    assert not hasattr(mb, "_seld_master_weights")
+    gru = [m for m in mb.modules() if isinstance(m, SeldGRU)][0]
+    assert gru.weight_ih_l0.dtype == torch.float32
+
+
+def test_multi_cast_matches_torch(gpu_device):
+    import seld_native
+    g = torch.Generator().manual_seed(0)
+    shapes = [(3,), (64, 4, 3, 3), (1536, 2048), (7, 5), (9072, 512), (1,)] * 20          # 120 tensors: two launches
+    src = [torch.randn(*s, generator=g).to(gpu_device) for s in shapes]
+    src[1] = src[1].contiguous(memory_format=torch.channels_last)
+    low = [torch.empty_like(s, dtype=torch.bfloat16) for s in src]
+    assert seld_native.multi_cast(src, low)
+    for a, b in zip(src, low):
+        assert torch.equal(a.to(torch.bfloat16), b)
+    back = [torch.empty_like(s) for s in src]
+    assert seld_native.multi_cast(low, back)
+    for a, b in zip(low, back):
+        assert torch.equal(a.float(), b)
+    # layout mismatch: refused, nothing written
+    bad = torch.zeros(64, 4, 3, 3, device=gpu_device, dtype=torch.bfloat16)             # NCHW vs channels-last source
+    assert not seld_native.multi_cast([src[1]], [bad]) and bad.abs().sum().item() == 0

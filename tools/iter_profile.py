@@ -13,6 +13,7 @@ trainer.config.MODEL_TYPE = sys.argv[2] if len(sys.argv) > 2 else "crnn"
 torch.manual_seed(0)
 model = trainer.prepare_model_for_device(trainer.build_model((18, 36)), dev).train()
 crit = trainer.SMRSELDLoss("mse", 1.0, grid_size=(18, 36))
+trainer.enable_master_weights(model, dev)
 opt = trainer.make_optimizer(model, 1e-3, dev)
 x = torch.randn(32, 250, 4, 64, device=dev) * 20 - 30
 mask = torch.zeros(32, 250, 648, dtype=torch.uint16, device=dev)
