@@ -129,7 +129,7 @@ def ensure_init(device) -> int:
     with _lock:
         if index in _initialised_devices:
             return index
-    with torch.cuda.device(index):
+    with _device_guard(index):
         check(lib.seld_init(index), "seld_init")
         fb = mel_filterbank()
         check(lib.seld_set_mel_filterbank(ctypes.c_void_p(fb.data_ptr())), "seld_set_mel_filterbank")
@@ -138,6 +138,24 @@ def ensure_init(device) -> int:
     with _lock:
         _initialised_devices.add(index)
     return index
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _device_guard(index: int):
+    """``torch.cuda.device(index)`` only when a switch is needed: one process drives one GPU (one rank per GPU), so
+    the current device is almost always right and the context manager's two runtime calls (~15 us of host time per
+    kernel launch on a launch-bound model) are skipped."""
+    return _NO_GUARD if torch.cuda.current_device() == index else torch.cuda.device(index)
 
 
 def num_frames(num_samples: int) -> int:
@@ -171,7 +189,7 @@ def logmel(pcm: torch.Tensor, layout: str = "cft", out: torch.Tensor | None = No
         raise ValueError(f"logmel: out must be contiguous float32 {shape}")
     lib = load_library()
     fn = lib.seld_logmel_f32 if pcm.dtype == torch.float32 else lib.seld_logmel_i16
-    with torch.cuda.device(index):
+    with _device_guard(index):
         check(fn(ctypes.c_void_p(pcm.data_ptr()), n, c, length, ctypes.c_void_p(out.data_ptr()), code,
                  _stream_ptr(pcm.device)), "seld_logmel")
     return out[0] if squeeze else out
@@ -208,7 +226,7 @@ def rasterise_labels(events: torch.Tensor, total_frames: int, I: int = GRID_I, J
         out = torch.empty((total_frames, I * J), dtype=torch.uint16, device=device)
     elif tuple(out.shape) != (total_frames, I * J) or out.dtype != torch.uint16 or not out.is_contiguous():
         raise ValueError("rasterise_labels: out must be a contiguous uint16 [total_frames, I*J] tensor")
-    with torch.cuda.device(index):
+    with _device_guard(index):
         check(load_library().seld_labels_rasterise(_p(ev), ev.shape[0], total_frames, I, J, _p(out),
                                                    _stream_ptr(device)), "seld_labels_rasterise")
     return out
@@ -248,7 +266,7 @@ def rasterise_labels_gaussian(events, centres, total_frames: int, I: int = GRID_
     if ctr.shape[0] != ev.shape[0]:
         raise ValueError("one box centre per metadata row")
     out = torch.empty((total_frames, I * J), dtype=torch.uint16, device=device)
-    with torch.cuda.device(index):
+    with _device_guard(index):
         check(load_library().seld_labels_rasterise_box(_p(ev), _p(ctr), ev.shape[0], total_frames, I, J, float(sigma_az),
                                                        float(sigma_el), _p(out), _stream_ptr(device)),
               "seld_labels_rasterise_box")
@@ -262,7 +280,7 @@ def expand_labels(mask: torch.Tensor, num_classes: int = NUM_CLASSES) -> torch.T
     mask = mask.contiguous()
     index = ensure_init(mask.device)
     out = torch.empty(tuple(mask.shape) + (num_classes,), dtype=torch.float32, device=mask.device)
-    with torch.cuda.device(index):
+    with _device_guard(index):
         check(load_library().seld_labels_expand(_p(mask), mask.numel(), num_classes, _p(out),
                                                 _stream_ptr(mask.device)), "seld_labels_expand")
     return out
@@ -279,7 +297,7 @@ def gather_windows(src: torch.Tensor, starts: torch.Tensor, window: int) -> torc
     out = torch.empty((starts.numel(), window) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
     if row_bytes == 0:
         raise ValueError("gather_windows: empty source")
-    with torch.cuda.device(index):
+    with _device_guard(index):
         check(load_library().seld_window_gather(_p(src), src.shape[0], row_bytes, _p(starts), starts.numel(),
                                                 window, _p(out), _stream_ptr(src.device)), "seld_window_gather")
     return out
@@ -321,7 +339,7 @@ def softmax_mse(logits: torch.Tensor, labels: torch.Tensor, grad_scale: float | 
         mask_p, dense_p = None, _p(labels)
     loss = torch.empty(1, dtype=torch.float32, device=logits.device)
     grad = torch.empty_like(logits) if grad_scale is not None else None
-    with torch.cuda.device(index):
+    with _device_guard(index):
         check(load_library().seld_softmax_mse(_p(logits), int(logits.dtype == torch.bfloat16), mask_p, dense_p,
                                               n_cells, m, float(grad_scale or 0.0), _p(loss), _p(grad),
                                               _p(_workspace(logits.device)), _stream_ptr(logits.device)),
@@ -336,7 +354,7 @@ def scale_by_device_scalar_(data: torch.Tensor, scale: torch.Tensor) -> torch.Te
             or data.numel() % 8 or data.data_ptr() % 16 or scale.numel() != 1):
         return data.mul_(scale.to(data.dtype))
     scale = scale.reshape(1).to(device=data.device, dtype=torch.float32)
-    with torch.cuda.device(ensure_init(data.device)):
+    with _device_guard(ensure_init(data.device)):
         check(load_library().seld_scale_by_device_scalar(_p(data), int(data.dtype == torch.bfloat16), data.numel(),
                                                          _p(scale), _stream_ptr(data.device)),
               "seld_scale_by_device_scalar")
@@ -369,7 +387,7 @@ def multi_cast(srcs, dsts) -> bool:
     dst = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts])
     lengths = (ctypes.c_int64 * n)(*[s.numel() for s in srcs])
     device = srcs[0].device
-    with torch.cuda.device(ensure_init(device)):
+    with _device_guard(ensure_init(device)):
         check(load_library().seld_multi_cast(src, dst, lengths, n, int(to_float), _stream_ptr(device)), "seld_multi_cast")
     return True
 
@@ -407,7 +425,7 @@ def conv_tail_forward(x, weight, bias, running_mean, running_var, momentum, eps,
     stats = torch.empty((2, 2, c), dtype=torch.float32, device=x.device)
     lib = load_library()
     ws = torch.empty(lib.seld_conv_tail_workspace_floats(c), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(index):
+    with _device_guard(index):
         check(lib.seld_conv_tail_forward(_p(x), _p(residual), int(x.dtype == torch.bfloat16), rows, c, pool, _p(weight),
                                          _p(bias),
                                          _p(running_mean), _p(running_var), float(momentum), float(eps), int(training),
@@ -427,7 +445,7 @@ def conv_tail_backward(x, dy, mean_invstd, scale_shift, pool, residual=None):
     dwb = torch.empty((2, c), dtype=torch.float32, device=x.device)
     lib = load_library()
     ws = torch.empty(lib.seld_conv_tail_workspace_floats(c), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(index):
+    with _device_guard(index):
         check(lib.seld_conv_tail_backward(_p(x), _p(residual), _p(dy), int(x.dtype == torch.bfloat16), rows, c, pool,
                                           _p(mean_invstd), _p(scale_shift), _p(dx), _p(dres), _p(dwb[0]), _p(dwb[1]),
                                           _p(ws), _stream_ptr(x.device)), "seld_conv_tail_backward")
@@ -493,7 +511,7 @@ def to_tile_device(x: torch.Tensor, ns: int) -> torch.Tensor:
     tiles = (b + seqs - 1) // seqs
     x = x.contiguous()
     out = torch.empty((tiles, t, 2, 8, ns, 4, parts, seqs, units), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(ensure_init(x.device)):
+    with _device_guard(ensure_init(x.device)):
         check(load_library().seld_gru_to_tile(_p(x), x.element_size(), b, t, ns, _p(out), _stream_ptr(x.device)),
               "seld_gru_to_tile")
     return out
@@ -504,7 +522,7 @@ def from_pair_tile_device(x: torch.Tensor, batch: int):
     t = x.shape[1]
     dgi = torch.empty((batch, t, 2, 3, GRU_H), dtype=x.dtype, device=x.device)
     dghn = torch.empty((batch, t, 2, GRU_H), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(ensure_init(x.device)):
+    with _device_guard(ensure_init(x.device)):
         check(load_library().seld_gru_from_pair_tile(_p(x), x.element_size(), batch, t, _p(dgi), _p(dghn),
                                                      _stream_ptr(x.device)), "seld_gru_from_pair_tile")
     return dgi, dghn
@@ -531,7 +549,7 @@ def gru_forward(gi: torch.Tensor, w_hh: torch.Tensor, b_hn: torch.Tensor, need_s
     saved_dtype = torch.float16 if gi.dtype == torch.bfloat16 else torch.float32      # see include/seld_hip.h
     saved = torch.empty((tiles, t, 2, 8, 2, 64, 2, 8 * GRU_TILE // 16), dtype=saved_dtype, device=gi.device) \
         if need_saved else None
-    with torch.cuda.device(index):
+    with _device_guard(index):
         check(load_library().seld_gru_forward(_p(gi_tile), int(gi.dtype == torch.bfloat16), _p(w), _p(bias), tiles, t,
                                               h, _p(y), _p(saved), _stream_ptr(gi.device)), "seld_gru_forward")
     return y[:b], saved
@@ -556,7 +574,7 @@ def gru_backward(dy: torch.Tensor, saved: torch.Tensor, y: torch.Tensor, w_hh: t
     dg_tile = torch.empty((tiles, t, 2, 8, 2, 4, 16 // GRU_TILE, GRU_TILE, 2, 8 * GRU_TILE // 16), dtype=dy.dtype,
                           device=dy.device)
     dbias = torch.empty((tiles, 2, 4, h), dtype=torch.float32, device=dy.device)
-    with torch.cuda.device(index):
+    with _device_guard(index):
         check(load_library().seld_gru_backward(_p(dy_tile), _p(saved), _p(y), int(dy.dtype == torch.bfloat16),
                                                _p(w_t), tiles, t, h, _p(dg_tile), _p(dbias), _stream_ptr(dy.device)),
               "seld_gru_backward")
@@ -583,7 +601,7 @@ def stft(pcm: torch.Tensor) -> torch.Tensor:
     index = ensure_init(pcm.device)
     out = torch.empty((n, c, num_frames(length), N_BINS, 2), dtype=torch.float32, device=pcm.device)
     fn = load_library().seld_stft_f32 if pcm.dtype == torch.float32 else load_library().seld_stft_i16
-    with torch.cuda.device(index):
+    with _device_guard(index):
         check(fn(_p(pcm), n, c, length, _p(out), _stream_ptr(pcm.device)), "seld_stft")
     spec = torch.view_as_complex(out)
     return spec[0] if squeeze else spec
@@ -616,7 +634,7 @@ def spatial_features(pcm: torch.Tensor, kind: str) -> torch.Tensor:
     s_n, s_t, s_c, s_m = frames * total * N_MELS, total * N_MELS, N_MELS, 1
     lib = load_library()
     stream = _stream_ptr(pcm.device)
-    with torch.cuda.device(index):
+    with _device_guard(index):
         fn = lib.seld_logmel_f32_strided if pcm.dtype == torch.float32 else lib.seld_logmel_i16_strided
         check(fn(_p(pcm), n, c, length, _p(out), s_n, s_c, s_m, s_t, stream), "seld_logmel_strided")
         spec = torch.view_as_real(stft(pcm))                                  # [N, C, F, 481, 2]
