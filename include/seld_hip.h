@@ -159,6 +159,17 @@ int seld_conv_tail_backward(const void* x, const void* residual, const void* dy,
                             int pool, const float* mean_invstd, const float* scale_shift, void* dx, void* dresidual,
                             float* dweight, float* dbias, float* workspace, void* stream);
 
+/* ---- Conformer convolution module: depthwise Conv1d over time, model_conformer.py:71-96 ------------------- */
+/* nn.Conv1d(D, D, K, padding=(K-1)/2, groups=D) evaluated in the channels-last layout of the surrounding layers:
+ * x, y [B][T][D] (bf16 when is_bf16, else fp32), weight [D][K] fp32, bias [D] fp32 or NULL, odd K <= 31, D % 64 == 0.
+ * flip_taps != 0 evaluates the data gradient (dx from dy with the taps reversed; pass bias = NULL).
+ * seld_dwconv1d_wgrad: partial [B][D][32] fp32 -- per batch row, slots 0..K-1 = sum_t dy[t] x[t + k - pad], slot 31 =
+ * sum_t dy[t]; the caller adds the batch rows (dweight = partial.sum(0)[:, :K], dbias = partial.sum(0)[:, 31]). */
+int seld_dwconv1d(const void* x, int is_bf16, const float* weight, const float* bias, int64_t B, int64_t T, int D, int K,
+                  int flip_taps, void* y, void* stream);
+int seld_dwconv1d_wgrad(const void* x, const void* dy, int is_bf16, int64_t B, int64_t T, int D, int K, float* partial,
+                        void* stream);
+
 /* ---- recurrence: nn.GRU(2048, 256, num_layers=2, bidirectional) at model_crnn.py:65-72 ------- */
 /* One bidirectional GRU layer's recurrence, all T steps in one launch (both directions), H = 256.
  * The batch is processed in tiles of S = seld_gru_tile_rows() sequences (4 in this build; pad B up to a whole

@@ -83,6 +83,10 @@ class ConformerConvModule(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x):
+        if x.is_cuda:
+            import seld_dwconv
+            if seld_dwconv.applicable(self, x):                       # channels-last evaluation (csrc/dwconv.hip)
+                return seld_dwconv.conv_module_forward(self, x)
         y = self.layer_norm(x).transpose(1, 2)                       # [B, D, T]
         y = self.glu(self.pointwise_conv1(y))
         y = self.swish(self.batch_norm(self.depthwise_conv(y)))

@@ -71,6 +71,8 @@ def _declare(lib):
                                            ctypes.c_float, _int, _ptr, _ptr, _ptr, _ptr, _ptr]
     lib.seld_conv_tail_backward.argtypes = [_ptr, _ptr, _ptr, _int, _i64, _int, _int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                                             _ptr, _ptr]
+    lib.seld_dwconv1d.argtypes = [_ptr, _int, _ptr, _ptr, _i64, _i64, _int, _int, _int, _ptr, _ptr]
+    lib.seld_dwconv1d_wgrad.argtypes = [_ptr, _ptr, _int, _i64, _i64, _int, _int, _ptr, _ptr]
     lib.seld_gru_to_tile.argtypes = [_ptr, _int, _i64, _i64, _int, _ptr, _ptr]
     lib.seld_gru_from_pair_tile.argtypes = [_ptr, _int, _i64, _i64, _ptr, _ptr, _ptr]
     lib.seld_gru_tile_rows.restype = _i64
@@ -452,6 +454,39 @@ def conv_tail_backward(x, dy, mean_invstd, scale_shift, pool, residual=None):
     if residual is not None:
         return dx, dwb[0], dwb[1], dres
     return dx, dwb[0], dwb[1]
+
+
+# --------------------------------------------------------------------------- depthwise Conv1d (Conformer conv module)
+
+def dwconv1d_supported(d: int, k: int) -> bool:
+    return d % 64 == 0 and 1 <= k <= 31 and k % 2 == 1
+
+
+def dwconv1d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None, flip: bool = False) -> torch.Tensor:
+    """Depthwise Conv1d over time on channels-last activations: x [B, T, D], weight [D, K] (fp32), bias [D] or None."""
+    if not x.is_cuda or x.dim() != 3 or x.dtype not in (torch.float32, torch.bfloat16):
+        raise SeldNativeError("dwconv1d: x must be a GPU tensor [B, T, D] of float32 or bfloat16")
+    x = x.contiguous()
+    b, t, d = x.shape
+    w = weight.to(torch.float32).contiguous()
+    bias = None if bias is None else bias.to(torch.float32).contiguous()
+    y = torch.empty_like(x)
+    with _device_guard(ensure_init(x.device)):
+        check(load_library().seld_dwconv1d(_p(x), int(x.dtype == torch.bfloat16), _p(w), _p(bias), b, t, d, w.shape[1],
+                                           int(flip), _p(y), _stream_ptr(x.device)), "seld_dwconv1d")
+    return y
+
+
+def dwconv1d_wgrad(x: torch.Tensor, dy: torch.Tensor, k: int):
+    """-> (dweight [D, K] fp32, dbias [D] fp32) of the depthwise convolution."""
+    x, dy = x.contiguous(), dy.to(x.dtype).contiguous()
+    b, t, d = x.shape
+    partial = torch.empty((b, d, 32), dtype=torch.float32, device=x.device)
+    with _device_guard(ensure_init(x.device)):
+        check(load_library().seld_dwconv1d_wgrad(_p(x), _p(dy), int(x.dtype == torch.bfloat16), b, t, d, k, _p(partial),
+                                                 _stream_ptr(x.device)), "seld_dwconv1d_wgrad")
+    total = partial.sum(dim=0)
+    return total[:, :k], total[:, 31]
 
 
 # --------------------------------------------------------------------------- GRU recurrence
