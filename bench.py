@@ -118,7 +118,9 @@ class HotPath:
         cfg.MODEL_TYPE = args.model
         cfg.BATCH_SIZE = BATCH
         cfg.AMP_DTYPE = "fp32" if args.fp32 else "bf16"
-        torch.manual_seed(0)
+        # identical initial weights on every rank; the gloo rehearsal mode seeds the ranks DIFFERENTLY on purpose so
+        # that it exercises what makes them agree (DDP's parameter broadcast + the master-weight broadcast)
+        torch.manual_seed(rank if os.environ.get("SELD_DIST_BACKEND", "nccl") != "nccl" else 0)
         self.features, self.channels = args.features, args.channels
         extra = {"logmel": 0, "logmel_iv": 3, "logmel_gcc": args.channels * (args.channels - 1) // 2}[args.features]
         self.feature_channels = args.channels + extra
@@ -337,6 +339,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    in_sync = None
+    if world > 1:       # every replica must hold the same weights after the timed steps (sum of all parameters)
+        with torch.no_grad():
+            total = sum(p.double().sum() for p in hot.model.parameters()).reshape(1)
+        hi, lo = total.clone(), total.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        in_sync = bool((hi - lo).abs().item() <= 1e-9 * max(1.0, abs(hi.item())))
     if rank == 0:
         feat_ms = float(np.mean([a.elapsed_time(b) for a, b in hot.feat_events]))
         model_ms = float(np.mean([a.elapsed_time(b) for a, b in hot.model_events]))
@@ -376,6 +386,8 @@ def main():
                                "bound": "mfma", "achieved": model_tflops, "peak": MFMA_BF16_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": model_tflops / MFMA_BF16_PEAK_TFLOPS, "avg_ms": model_ms},
         }
+        if in_sync is not None:
+            line["config"]["replicas_in_sync"] = in_sync
         if hasattr(hot.optimizer, "fused_casts"):
             line["config"]["master_weights"] = {"one_launch_gradient_casts": hot.optimizer.fused_casts,
                                                 "per_tensor_fallbacks": hot.optimizer.fallback_casts}

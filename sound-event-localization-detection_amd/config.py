@@ -91,6 +91,8 @@ class Config:
     CHANNELS_LAST = True        # NHWC conv blocks (MIOpen/hipBLASLt MFMA path)
     FUSED_LOSS = True           # seld_softmax_mse instead of softmax + mse_loss + autograd
     FUSED_CONV_TAIL = True      # BatchNorm -> ReLU -> MaxPool of the CNN blocks in two HBM passes (csrc/convtail.hip)
+    FUSED_DWCONV = False        # channels-last Conformer conv module with the HIP depthwise Conv1d (csrc/dwconv.hip):
+                                # fewer GPU microseconds but more host work -- pays only when the step is GPU-bound
     FUSED_GRU = True            # persistent BiGRU kernel instead of MIOpen's per-step GEMMs
     DEVICE_FEED = True          # train from device-resident features / compact labels (no 290 MB/step H2D)
     MASTER_WEIGHTS = True       # bf16 runs: the conv / Linear / GRU weight matrices live in the model as bf16 working

@@ -2,13 +2,18 @@
 Conformer convolution module (model_conformer.py:71-96) built on it: the module's two pointwise Conv1d layers are
 Linear layers on [B, T, D] (same parameters, kernel-size-1 weights squeezed), GLU / BatchNorm1d / Swish act on the
 last dimension, and no [B, T, D] <-> [B, D, T] transposes are needed."""
+import os
+
 import torch
 import torch.nn.functional as F
 
 import seld_native
 from seld_linear import _Linear
 
-enabled = True
+# Off by default: measured on the bs-32 Conformer (a host-launch-bound step, 55 % GPU-busy) the extra host work of this
+# path costs more than its shorter GPU time gains (A/B on one box: 61.6 / 72.2 clips/s on vs 65.3 / 78.0 off); it pays
+# when the step is GPU-bound.  Config.FUSED_DWCONV (via trainer.prepare_model_for_device) or SELD_DWCONV=1 turn it on.
+enabled = os.environ.get("SELD_DWCONV", "0") == "1"
 
 
 class _DepthwiseConv1d(torch.autograd.Function):

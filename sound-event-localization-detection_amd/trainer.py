@@ -89,6 +89,9 @@ def prepare_model_for_device(model, device):
         import seld_convtail
         import seld_gru
         seld_convtail.enabled = bool(getattr(config, "FUSED_CONV_TAIL", True))
+        if getattr(config, "FUSED_DWCONV", False):
+            import seld_dwconv
+            seld_dwconv.enabled = True
         for module in model.modules():
             if isinstance(module, SeldGRU) and SeldGRU.fused_enabled:
                 seld_gru.pack_parameters(module)
@@ -133,7 +136,18 @@ def wrap_ddp(model, device, world):
                   broadcast_buffers=False)
     if device.type == "cuda":
         kwargs.update(device_ids=[device.index], output_device=device.index)
-    return torch.nn.parallel.DistributedDataParallel(model, **kwargs)
+    ddp = torch.nn.parallel.DistributedDataParallel(model, **kwargs)
+    # DDP has just broadcast rank 0's parameters -- the bf16 working copies included.  The fp32 masters behind them
+    # are not module parameters: broadcast them too (the reference never seeds, so every rank initialised its own)
+    # and re-derive the working copies, or the ranks would part ways at the first optimiser step.
+    state = getattr(model, "_seld_master_weights", None)
+    if state is not None:
+        with torch.no_grad():
+            for master in state[1]:
+                dist.broadcast(master, src=0)
+            for p, master in zip(state[0], state[1]):
+                p.data.copy_(master)
+    return ddp
 
 
 def all_reduce_sums(values, device):

@@ -39,13 +39,15 @@ def test_conformer_conv_module_channels_last_equals_stock(gpu_device):
     stock.load_state_dict(fused.state_dict())
     x = torch.randn(4, 50, 256, device=gpu_device)
     xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
-    assert seld_dwconv.applicable(fused, xa)
-    y = fused(xa)
-    seld_dwconv.enabled = False
+    was = seld_dwconv.enabled
     try:
+        seld_dwconv.enabled = True
+        assert seld_dwconv.applicable(fused, xa)
+        y = fused(xa)
+        seld_dwconv.enabled = False
         y_ref = stock(xb)
     finally:
-        seld_dwconv.enabled = True
+        seld_dwconv.enabled = was
     assert (y - y_ref).abs().max().item() <= 1e-4 * y_ref.abs().max().item()
     go = torch.randn_like(y)
     y.backward(go)
@@ -53,6 +55,9 @@ def test_conformer_conv_module_channels_last_equals_stock(gpu_device):
     assert (xa.grad - xb.grad).abs().max().item() <= 1e-4 * xb.grad.abs().max().item()
     for (n, p), (_, q) in zip(fused.named_parameters(), stock.named_parameters()):
         assert p.grad.shape == q.grad.shape
+        if n == "depthwise_conv.bias":          # feeds a training-mode BatchNorm: its exact gradient is zero, both are noise
+            assert p.grad.abs().max().item() <= 1e-3 and q.grad.abs().max().item() <= 1e-3
+            continue
         assert (p.grad - q.grad).abs().max().item() <= 5e-4 * (q.grad.abs().max().item() + 1e-6), n
     for (n, p), (_, q) in zip(fused.named_buffers(), stock.named_buffers()):
         assert torch.allclose(p.float(), q.float(), rtol=1e-4, atol=1e-5), n
