@@ -98,7 +98,8 @@ class Config:
     MASTER_WEIGHTS = True       # bf16 runs: the conv / Linear / GRU weight matrices live in the model as bf16 working
                                 # copies of fp32 masters owned by the optimiser (same values autocast would cast to
                                 # every iteration, without ~40-340 cast kernels per iteration; bf16 gradient all-reduce)
-    DDP_BUCKET_MB = 25          # RCCL all-reduce bucket size
+    DDP_BUCKET_MB = 8           # RCCL all-reduce bucket size: with bf16 working weights the CRNN's gradients are 22 MB, so
+                                # 8 MB gives three buckets -- the head's (ready first) reduces under the GRU / conv backward
     SYNC_BATCHNORM = False      # per-rank BN statistics by default
     SEED = None                 # the reference never seeds; set an int for reproducible runs
     FEATURE_SET = "logmel"      # 'logmel' (the reference) | 'logmel_iv' (FOA: + 3 intensity-vector channels) |
