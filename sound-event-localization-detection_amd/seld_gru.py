@@ -58,7 +58,8 @@ class _BiGRULayer(torch.autograd.Function):
             dgi2 = dgi.view(n, 6 * h)                                             # d/d(gi), both directions
             x2 = xc.reshape(n, -1)
             dx = (dgi2 @ w_ih.to(cdt)).view_as(xc)
-            dw_ih = tall_product(dgi2, x2)                                       # [6H, In] fp32
+            t_wih, t_bih, t_whh, t_bhh = ctx.dtypes
+            dw_ih = tall_product(dgi2, x2, out_dtype=t_wih)                      # [6H, In]
             db_ih = dbias[:, :3].reshape(-1)
             db_hh = torch.cat((dbias[:, :2], dbias[:, 3:]), dim=1).reshape(2, 3 * h)
             # h_{t-1} of the forward recurrence: y shifted by one step in each direction's own time order
@@ -72,11 +73,10 @@ class _BiGRULayer(torch.autograd.Function):
             # d/d(gh) = (da_r, da_z, da_n * r).  Two well-shaped products instead of eight skinny ones: all of dgi
             # and dghn against both directions' h_prev; the wanted blocks are those with matching directions (the
             # cross-direction blocks and dgi's n rows are computed and dropped: ~6 GFLOP, cheaper than the launches).
-            p_gi = tall_product(dgi2, hp).view(2, 3, h, 2, h)                    # [dir, gate, unit, dir', unit']
-            p_n = tall_product(dghn.view(n, 2 * h), hp).view(2, h, 2, h)
+            p_gi = tall_product(dgi2, hp, out_dtype=t_whh).view(2, 3, h, 2, h)   # [dir, gate, unit, dir', unit']
+            p_n = tall_product(dghn.view(n, 2 * h), hp, out_dtype=t_whh).view(2, h, 2, h)
             dw_hh = torch.stack([torch.cat((p_gi[d, :2, :, d].reshape(2 * h, h), p_n[d, :, d]), dim=0)
                                  for d in range(2)], dim=0)
-        t_wih, t_bih, t_whh, t_bhh = ctx.dtypes
         return dx.to(dy.dtype) if dx.dtype != dy.dtype and not torch.is_autocast_enabled() else dx, \
             dw_ih.to(t_wih), db_ih.to(t_bih), dw_hh.to(t_whh), db_hh.to(t_bhh)
 

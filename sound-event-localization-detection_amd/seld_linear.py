@@ -14,8 +14,10 @@ import torch.nn.functional as F
 enabled = True
 
 
-def tall_product(a, c, min_tiles=256, max_chunks=16):
-    """a^T c for tall operands (a [N, G], c [N, K]) -> [G, K] fp32.  Row strides may be anything (column stride 1)."""
+def tall_product(a, c, min_tiles=256, max_chunks=16, out_dtype=torch.float32):
+    """a^T c for tall operands (a [N, G], c [N, K]) -> [G, K] in ``out_dtype``.  Row strides may be anything (column
+    stride 1).  With ``out_dtype`` = the operands' dtype (bf16 working weights) the GEMM / the partial-sum reduction
+    write the result directly (the reduction still accumulates in fp32): no separate cast kernels."""
     n, g = a.shape
     k = c.shape[1]
     chunks = 1
@@ -23,10 +25,11 @@ def tall_product(a, c, min_tiles=256, max_chunks=16):
            and n % (2 * chunks) == 0 and n // (2 * chunks) >= 64):
         chunks *= 2
     if chunks == 1:
-        return (a.t() @ c).float()
+        out = a.t() @ c
+        return out if out.dtype == out_dtype else out.to(out_dtype)
     av = a.unflatten(0, (chunks, n // chunks)).transpose(1, 2)                    # [chunks, G, N/chunks] view
     cv = c.unflatten(0, (chunks, n // chunks))
-    return torch.bmm(av, cv).float().sum(dim=0)
+    return torch.sum(torch.bmm(av, cv), dim=0, dtype=out_dtype)
 
 
 class _Linear(torch.autograd.Function):
@@ -50,7 +53,7 @@ class _Linear(torch.autograd.Function):
             g2 = grad.reshape(-1, grad.shape[-1]).to(xc.dtype)
             x2 = xc.reshape(-1, xc.shape[-1])
             dx = (g2 @ wc).view_as(xc) if ctx.needs_input_grad[0] else None
-            dw = tall_product(g2, x2) if ctx.needs_input_grad[1] else None
+            dw = tall_product(g2, x2, out_dtype=ctx.w_dtype) if ctx.needs_input_grad[1] else None
             db = torch.sum(g2, dim=0, dtype=torch.float32) if ctx.has_bias and ctx.needs_input_grad[2] else None
         if dx is not None and dx.dtype != ctx.in_dtype:
             dx = dx.to(ctx.in_dtype)
