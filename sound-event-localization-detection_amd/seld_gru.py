@@ -75,8 +75,10 @@ class _BiGRULayer(torch.autograd.Function):
             # cross-direction blocks and dgi's n rows are computed and dropped: ~6 GFLOP, cheaper than the launches).
             p_gi = tall_product(dgi2, hp, out_dtype=t_whh).view(2, 3, h, 2, h)   # [dir, gate, unit, dir', unit']
             p_n = tall_product(dghn.view(n, 2 * h), hp, out_dtype=t_whh).view(2, h, 2, h)
-            dw_hh = torch.stack([torch.cat((p_gi[d, :2, :, d].reshape(2 * h, h), p_n[d, :, d]), dim=0)
-                                 for d in range(2)], dim=0)
+            dw_hh = torch.empty((2, 3 * h, h), dtype=t_whh, device=dy.device)
+            for d in range(2):
+                dw_hh[d, :2 * h].view(2, h, h).copy_(p_gi[d, :2, :, d])
+                dw_hh[d, 2 * h:].copy_(p_n[d, :, d])
         return dx.to(dy.dtype) if dx.dtype != dy.dtype and not torch.is_autocast_enabled() else dx, \
             dw_ih.to(t_wih), db_ih.to(t_bih), dw_hh.to(t_whh), db_hh.to(t_bhh)
 
