@@ -91,6 +91,7 @@ class Config:
     CHANNELS_LAST = True        # NHWC conv blocks (MIOpen/hipBLASLt MFMA path)
     FUSED_LOSS = True           # seld_softmax_mse instead of softmax + mse_loss + autograd
     FUSED_CONV_TAIL = True      # BatchNorm -> ReLU -> MaxPool of the CNN blocks in two HBM passes (csrc/convtail.hip)
+    CONV_DGRAD_AS_FORWARD = True  # encoder 3x3 convs: data gradient as a forward conv with transposed, flipped weights
     FUSED_DWCONV = False        # channels-last Conformer conv module with the HIP depthwise Conv1d (csrc/dwconv.hip):
                                 # fewer GPU microseconds but more host work -- pays only when the step is GPU-bound
     FUSED_GRU = True            # persistent BiGRU kernel instead of MIOpen's per-step GEMMs

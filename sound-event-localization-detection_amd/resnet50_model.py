@@ -12,6 +12,7 @@ import torch.nn as nn
 from seld_linear import SeldLinear
 
 from model_conformer import ConformerBlock
+from model_crnn import conv3x3
 
 
 class Bottleneck(nn.Module):
@@ -36,7 +37,7 @@ class Bottleneck(nn.Module):
             import seld_convtail as tail           # fused BatchNorm -> [+ shortcut] -> ReLU (csrc/convtail.hip)
             y = self.conv1(x)
             y = tail.bn_relu(self.bn1, y) if tail.bn_applicable(self.bn1, y) else self.relu(self.bn1(y))
-            y = self.conv2(y)
+            y = conv3x3(self.conv2, y)            # stride-1 3x3: data gradient as a forward convolution
             y = tail.bn_relu(self.bn2, y) if tail.bn_applicable(self.bn2, y) else self.relu(self.bn2(y))
             y = self.conv3(y)
             if tail.bn_applicable(self.bn3, y) and shortcut.shape == y.shape and shortcut.dtype == y.dtype:

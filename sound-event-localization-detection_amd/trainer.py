@@ -89,6 +89,8 @@ def prepare_model_for_device(model, device):
         import seld_convtail
         import seld_gru
         seld_convtail.enabled = bool(getattr(config, "FUSED_CONV_TAIL", True))
+        import model_crnn
+        model_crnn._Conv3x3.enabled = bool(getattr(config, "CONV_DGRAD_AS_FORWARD", True))
         if getattr(config, "FUSED_DWCONV", False):
             import seld_dwconv
             seld_dwconv.enabled = True
