@@ -90,7 +90,8 @@ def prepare_model_for_device(model, device):
         import seld_gru
         seld_convtail.enabled = bool(getattr(config, "FUSED_CONV_TAIL", True))
         import model_crnn
-        model_crnn._Conv3x3.enabled = bool(getattr(config, "CONV_DGRAD_AS_FORWARD", True))
+        model_crnn._Conv3x3.enabled = bool(getattr(config, "CONV_DGRAD_AS_FORWARD", True)) and \
+            os.environ.get("SELD_CONV_AS_FWD", "1") != "0"          # developer switch for A/B runs
         if getattr(config, "FUSED_DWCONV", False):
             import seld_dwconv
             seld_dwconv.enabled = True
