@@ -98,14 +98,19 @@ def build_cnn_encoder(n_channels, n_mels, cnn_channels, max_pools=4):
     return blocks, channels, freq
 
 
-def run_cnn_encoder(blocks, x):
-    """[B, T, C, F] -> [B, T, C_out * F_out] (model_crnn.py:106-116)."""
+def run_cnn_blocks(blocks, x):
+    """[B, T, C, F] -> [B, C_out, T, F_out] (channels-last memory on a GPU)."""
     x = x.permute(0, 2, 1, 3)
     if x.is_cuda:
         x = x.contiguous(memory_format=torch.channels_last)
     for block in blocks:
         x = block(x)
-    x = x.permute(0, 2, 1, 3)
+    return x
+
+
+def run_cnn_encoder(blocks, x):
+    """[B, T, C, F] -> [B, T, C_out * F_out] (model_crnn.py:106-116)."""
+    x = run_cnn_blocks(blocks, x).permute(0, 2, 1, 3)
     return x.reshape(x.shape[0], x.shape[1], -1)
 
 
@@ -132,6 +137,16 @@ class SELD_CRNN(nn.Module):
     def forward(self, x):
         """x [B, T, C, F] -> logits [B, T, G, M]."""
         batch, frames = x.shape[0], x.shape[1]
-        feats = run_cnn_encoder(self.cnn_blocks, x)
+        y = run_cnn_blocks(self.cnn_blocks, x)                                  # [B, C, T, F]
+        if y.is_cuda and y.is_contiguous(memory_format=torch.channels_last) and SeldGRU.fused_enabled:
+            # channels-last memory is [B][T][F][C]: the (frequency, channel)-ordered feature vector is a VIEW of it.
+            # The HIP BiGRU path takes it as is and permutes the columns of layer 0's W_ih instead (6 MB of weights
+            # rather than two 33 MB activation copies, forward and backward); same numbers.
+            import seld_gru
+            feats_fc = y.permute(0, 2, 3, 1).reshape(batch, frames, -1)
+            if seld_gru.applicable(self.rnn, feats_fc):
+                feats, _ = seld_gru.bigru_forward(self.rnn, feats_fc, feature_cf=(y.shape[1], y.shape[3]))
+                return self.fnn(feats).view(batch, frames, self.grid_cells, self.num_classes)
+        feats = y.permute(0, 2, 1, 3).reshape(batch, frames, -1)                # (channel, frequency) order
         feats, _ = self.rnn(feats)
         return self.fnn(feats).view(batch, frames, self.grid_cells, self.num_classes)

@@ -125,14 +125,19 @@ def pack_parameters(module):
                 b.data = flat[a.numel():].view_as(b)
 
 
-def bigru_forward(module, x):
-    """Drop-in for ``nn.GRU.forward(x)`` with h0 = 0: returns (output [B,T,2H], h_n [2*layers,B,H])."""
+def bigru_forward(module, x, feature_cf=None):
+    """Drop-in for ``nn.GRU.forward(x)`` with h0 = 0: returns (output [B,T,2H], h_n [2*layers,B,H]).
+    ``feature_cf = (C, F)``: the input features are ordered (frequency, channel) -- f * C + c -- instead of the
+    parameters' (channel, frequency) order c * F + f; layer 0's W_ih columns are permuted to match."""
     out = x
     finals = []
     for layer in range(module.num_layers):
         p = lambda name: getattr(module, f"{name}_l{layer}")                      # noqa: E731
         pr = lambda name: getattr(module, f"{name}_l{layer}_reverse")             # noqa: E731
         w_ih = _join(p("weight_ih"), pr("weight_ih"))
+        if layer == 0 and feature_cf is not None:
+            c, f = feature_cf
+            w_ih = w_ih.view(w_ih.shape[0], c, f).transpose(1, 2).reshape(w_ih.shape[0], f * c)
         b_ih = _join(p("bias_ih"), pr("bias_ih"))
         w_hh = _join(p("weight_hh"), pr("weight_hh")).view(2, 3 * HIDDEN, HIDDEN)
         b_hh = _join(p("bias_hh"), pr("bias_hh")).view(2, 3 * HIDDEN)
