@@ -148,10 +148,11 @@ def test_device_code_has_no_vcc_scc_select_miscompile(tmp_path):
                         "-S", "--cuda-device-only", str(src), "-o", str(out)], check=True, capture_output=True)
         lines = out.read_text().splitlines()
         for i, line in enumerate(lines):
-            if "s_cselect" not in line:
+            if "s_cselect" not in line and "s_cbranch_scc" not in line:
                 continue
             j = i - 1
-            while j >= 0 and not scc_writer.match(lines[j]) and "s_cselect" not in lines[j] and not lines[j].strip().endswith(":"):
+            while j >= 0 and not scc_writer.match(lines[j]) and "s_cselect" not in lines[j] \
+                    and not lines[j].strip().endswith(":"):
                 j -= 1
             writer = lines[j].strip() if j >= 0 else ""
             wide_cmp = [x for x in lines[j + 1:i] if "v_cmp" in x and "64" in x]
