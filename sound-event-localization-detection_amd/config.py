@@ -92,8 +92,11 @@ class Config:
     FUSED_LOSS = True           # seld_softmax_mse instead of softmax + mse_loss + autograd
     FUSED_CONV_TAIL = True      # BatchNorm -> ReLU -> MaxPool of the CNN blocks in two HBM passes (csrc/convtail.hip)
     CONV_DGRAD_AS_FORWARD = True  # encoder 3x3 convs: data gradient as a forward conv with transposed, flipped weights
-    FUSED_DWCONV = False        # channels-last Conformer conv module with the HIP depthwise Conv1d (csrc/dwconv.hip):
-                                # fewer GPU microseconds but more host work -- pays only when the step is GPU-bound
+    FUSED_DWCONV = "auto"       # channels-last Conformer conv module with the HIP depthwise Conv1d (csrc/dwconv.hip):
+                                # fewer GPU microseconds but more host work; "auto" = modules with d_model >= 512 (measured
+                                # +3 % on the ResNet50-Conformer, -7 % on the host-bound d_model-256 Conformer)
+    OVERLAP_WEIGHT_GRADS = True  # CRNN: weight gradients of the head and of GRU layer 1 on a side HIP stream, under the
+                                # backward recurrences that occupy 16 of the 256 CUs (seld_overlap.py)
     FUSED_GRU = True            # persistent BiGRU kernel instead of MIOpen's per-step GEMMs
     DEVICE_FEED = True          # train from device-resident features / compact labels (no 290 MB/step H2D)
     MASTER_WEIGHTS = True       # bf16 runs: the conv / Linear / GRU weight matrices live in the model as bf16 working

@@ -143,9 +143,16 @@ class SELD_CRNN(nn.Module):
             # The HIP BiGRU path takes it as is and permutes the columns of layer 0's W_ih instead (6 MB of weights
             # rather than two 33 MB activation copies, forward and backward); same numbers.
             import seld_gru
+            import seld_overlap
             feats_fc = y.permute(0, 2, 3, 1).reshape(batch, frames, -1)
             if seld_gru.applicable(self.rnn, feats_fc):
-                feats, _ = seld_gru.bigru_forward(self.rnn, feats_fc, feature_cf=(y.shape[1], y.shape[3]))
+                # weight gradients of the head and of GRU layer 1 go to a side stream, under the backward recurrences
+                # (seld_overlap.py); their identity nodes have to be created here, before GRU layer 0's
+                overlap = seld_overlap.active(feats_fc) and self.training
+                if overlap:
+                    seld_overlap.defer_linear(self.fnn[0], self.fnn[4])
+                feats, _ = seld_gru.bigru_forward(self.rnn, feats_fc, feature_cf=(y.shape[1], y.shape[3]),
+                                                  overlap=overlap)
                 return self.fnn(feats).view(batch, frames, self.grid_cells, self.num_classes)
         feats = y.permute(0, 2, 1, 3).reshape(batch, frames, -1)                # (channel, frequency) order
         feats, _ = self.rnn(feats)

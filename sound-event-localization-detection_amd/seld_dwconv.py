@@ -10,10 +10,13 @@ import torch.nn.functional as F
 import seld_native
 from seld_linear import _Linear
 
-# Off by default: measured on the bs-32 Conformer (a host-launch-bound step, 55 % GPU-busy) the extra host work of this
-# path costs more than its shorter GPU time gains (A/B on one box: 61.6 / 72.2 clips/s on vs 65.3 / 78.0 off); it pays
-# when the step is GPU-bound.  Config.FUSED_DWCONV (via trainer.prepare_model_for_device) or SELD_DWCONV=1 turn it on.
-enabled = os.environ.get("SELD_DWCONV", "0") == "1"
+# "auto" (default): on for wide modules (d_model >= 512) only.  Measured A/B, same box, back to back: the bs-32
+# ResNet50-Conformer (d_model 512, 4 blocks, 80 % GPU-busy) gains 3 % (22.1 / 22.3 clips/s on vs 21.6 / 21.5 off), while
+# the bs-32 Conformer (d_model 256, host-launch bound at 55 % GPU-busy) LOSES 7 % (61.6 / 72.2 on vs 65.3 / 78.0 off):
+# this path trades GPU time for a little more host work.  Config.FUSED_DWCONV (True / False / "auto") via
+# trainer.prepare_model_for_device, or SELD_DWCONV=1 / 0, override.
+_env = os.environ.get("SELD_DWCONV")
+enabled = "auto" if _env is None else (_env == "1")
 
 
 class _DepthwiseConv1d(torch.autograd.Function):
@@ -39,7 +42,8 @@ class _DepthwiseConv1d(torch.autograd.Function):
 def applicable(module, x):
     dw = module.depthwise_conv
     k = dw.kernel_size[0]
-    return (enabled and x.is_cuda and x.dim() == 3 and x.dtype in (torch.float32, torch.bfloat16)
+    on = enabled is True or (enabled == "auto" and dw.in_channels >= 512)
+    return (on and x.is_cuda and x.dim() == 3 and x.dtype in (torch.float32, torch.bfloat16)
             and dw.groups == dw.in_channels == dw.out_channels and dw.stride == (1,) and dw.dilation == (1,)
             and dw.padding == ((k - 1) // 2,) and dw.padding_mode == "zeros"
             and seld_native.dwconv1d_supported(dw.in_channels, k)

@@ -11,6 +11,7 @@ import torch
 import torch.nn.functional as F
 
 import seld_native
+import seld_overlap
 from seld_linear import tall_product
 
 HIDDEN = 256
@@ -28,8 +29,10 @@ def applicable(module, x):
 
 class _BiGRULayer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_ih, b_ih, w_hh, b_hh):
-        """x [B,T,In]; w_ih [6H,In]; b_ih [6H]; w_hh [2,3H,H]; b_hh [2,3H]."""
+    def forward(ctx, x, w_ih, b_ih, w_hh, b_hh, overlap=False):
+        """x [B,T,In]; w_ih [6H,In]; b_ih [6H]; w_hh [2,3H,H]; b_hh [2,3H].  ``overlap``: the parameters are
+        ``seld_overlap.defer`` aliases -- their weight gradients may be produced on the side stream."""
+        ctx.overlap = overlap
         low = torch.is_autocast_enabled() or x.dtype == torch.bfloat16
         cdt = torch.bfloat16 if low else torch.float32
         with torch.autocast(device_type="cuda", enabled=False):
@@ -57,30 +60,42 @@ class _BiGRULayer(torch.autograd.Function):
             dgi, dghn, dbias = seld_native.gru_backward(dy.to(y.dtype), saved, y, w_hh)
             dgi2 = dgi.view(n, 6 * h)                                             # d/d(gi), both directions
             x2 = xc.reshape(n, -1)
-            dx = (dgi2 @ w_ih.to(cdt)).view_as(xc)
             t_wih, t_bih, t_whh, t_bhh = ctx.dtypes
-            dw_ih = tall_product(dgi2, x2, out_dtype=t_wih)                      # [6H, In]
+
+            def weight_grads():
+                dw_ih = tall_product(dgi2, x2, out_dtype=t_wih)                  # [6H, In]
+                # h_{t-1} of the forward recurrence: y shifted by one step in each direction's own time order
+                yv = y.view(b, t, 2, h)
+                h_prev = torch.empty_like(yv)
+                h_prev[:, 1:, 0] = yv[:, :-1, 0]
+                h_prev[:, :-1, 1] = yv[:, 1:, 1]
+                h_prev[:, 0, 0] = 0
+                h_prev[:, -1, 1] = 0
+                hp = h_prev.view(n, 2 * h)
+                # d/d(gh) = (da_r, da_z, da_n * r).  Two well-shaped products instead of eight skinny ones: all of
+                # dgi and dghn against both directions' h_prev; the wanted blocks are those with matching directions
+                # (the cross-direction blocks and dgi's n rows are computed and dropped: ~6 GFLOP, cheaper than the
+                # launches).
+                p_gi = tall_product(dgi2, hp, out_dtype=t_whh).view(2, 3, h, 2, h)   # [dir, gate, unit, dir', unit']
+                p_n = tall_product(dghn.view(n, 2 * h), hp, out_dtype=t_whh).view(2, h, 2, h)
+                dw_hh = torch.empty((2, 3 * h, h), dtype=t_whh, device=dy.device)
+                for d in range(2):
+                    dw_hh[d, :2 * h].view(2, h, h).copy_(p_gi[d, :2, :, d])
+                    dw_hh[d, 2 * h:].copy_(p_n[d, :, d])
+                return dw_ih, dw_hh
+
+            if ctx.overlap:
+                # side stream (seld_overlap): hidden under the data-gradient GEMM and the NEXT layer's recurrence
+                with seld_overlap.fork(dy.device, dgi, dghn, y, xc) as f:
+                    dw_ih, dw_hh = weight_grads()
+                    f.outputs(dw_ih, dw_hh)
+            dx = (dgi2 @ w_ih.to(cdt)).view_as(xc)
+            if not ctx.overlap:
+                dw_ih, dw_hh = weight_grads()
             db_ih = dbias[:, :3].reshape(-1)
             db_hh = torch.cat((dbias[:, :2], dbias[:, 3:]), dim=1).reshape(2, 3 * h)
-            # h_{t-1} of the forward recurrence: y shifted by one step in each direction's own time order
-            yv = y.view(b, t, 2, h)
-            h_prev = torch.empty_like(yv)
-            h_prev[:, 1:, 0] = yv[:, :-1, 0]
-            h_prev[:, :-1, 1] = yv[:, 1:, 1]
-            h_prev[:, 0, 0] = 0
-            h_prev[:, -1, 1] = 0
-            hp = h_prev.view(n, 2 * h)
-            # d/d(gh) = (da_r, da_z, da_n * r).  Two well-shaped products instead of eight skinny ones: all of dgi
-            # and dghn against both directions' h_prev; the wanted blocks are those with matching directions (the
-            # cross-direction blocks and dgi's n rows are computed and dropped: ~6 GFLOP, cheaper than the launches).
-            p_gi = tall_product(dgi2, hp, out_dtype=t_whh).view(2, 3, h, 2, h)   # [dir, gate, unit, dir', unit']
-            p_n = tall_product(dghn.view(n, 2 * h), hp, out_dtype=t_whh).view(2, h, 2, h)
-            dw_hh = torch.empty((2, 3 * h, h), dtype=t_whh, device=dy.device)
-            for d in range(2):
-                dw_hh[d, :2 * h].view(2, h, h).copy_(p_gi[d, :2, :, d])
-                dw_hh[d, 2 * h:].copy_(p_n[d, :, d])
         return dx.to(dy.dtype) if dx.dtype != dy.dtype and not torch.is_autocast_enabled() else dx, \
-            dw_ih.to(t_wih), db_ih.to(t_bih), dw_hh.to(t_whh), db_hh.to(t_bhh)
+            dw_ih, db_ih.to(t_bih), dw_hh, db_hh.to(t_bhh), None
 
 
 class _Joined(torch.autograd.Function):
@@ -125,23 +140,30 @@ def pack_parameters(module):
                 b.data = flat[a.numel():].view_as(b)
 
 
-def bigru_forward(module, x, feature_cf=None):
+def bigru_forward(module, x, feature_cf=None, overlap=False):
     """Drop-in for ``nn.GRU.forward(x)`` with h0 = 0: returns (output [B,T,2H], h_n [2*layers,B,H]).
     ``feature_cf = (C, F)``: the input features are ordered (frequency, channel) -- f * C + c -- instead of the
-    parameters' (channel, frequency) order c * F + f; layer 0's W_ih columns are permuted to match."""
-    out = x
-    finals = []
+    parameters' (channel, frequency) order c * F + f; layer 0's W_ih columns are permuted to match.
+    ``overlap``: weight gradients of layers >= 1 on the side stream (seld_overlap)."""
+    overlap = overlap and seld_overlap.active(x)
+    params = []
     for layer in range(module.num_layers):
         p = lambda name: getattr(module, f"{name}_l{layer}")                      # noqa: E731
         pr = lambda name: getattr(module, f"{name}_l{layer}_reverse")             # noqa: E731
-        w_ih = _join(p("weight_ih"), pr("weight_ih"))
+        group = (_join(p("weight_ih"), pr("weight_ih")), _join(p("bias_ih"), pr("bias_ih")),
+                 _join(p("weight_hh"), pr("weight_hh")), _join(p("bias_hh"), pr("bias_hh")))
+        # layers >= 1: their weight gradients hide under the recurrence of the layer below.  The identity node must
+        # exist BEFORE layer 0's node (see seld_overlap); layer 0's own would only compete with the convolutions.
+        params.append(seld_overlap.defer(*group) if overlap and layer > 0 else group)
+    out = x
+    finals = []
+    for layer in range(module.num_layers):
+        w_ih, b_ih, w_hh, b_hh = params[layer]
         if layer == 0 and feature_cf is not None:
             c, f = feature_cf
             w_ih = w_ih.view(w_ih.shape[0], c, f).transpose(1, 2).reshape(w_ih.shape[0], f * c)
-        b_ih = _join(p("bias_ih"), pr("bias_ih"))
-        w_hh = _join(p("weight_hh"), pr("weight_hh")).view(2, 3 * HIDDEN, HIDDEN)
-        b_hh = _join(p("bias_hh"), pr("bias_hh")).view(2, 3 * HIDDEN)
-        out = _BiGRULayer.apply(out, w_ih, b_ih, w_hh, b_hh)
+        out = _BiGRULayer.apply(out, w_ih, b_ih, w_hh.view(2, 3 * HIDDEN, HIDDEN), b_hh.view(2, 3 * HIDDEN),
+                                overlap and layer > 0)
         finals += [out[:, -1, :HIDDEN], out[:, 0, HIDDEN:]]
         if module.training and module.dropout > 0 and layer + 1 < module.num_layers:
             out = F.dropout(out, p=module.dropout, training=True)

@@ -11,6 +11,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import seld_overlap
+
 enabled = True
 
 
@@ -37,7 +39,8 @@ def tall_product(a, c, out_dtype=torch.float32):
 
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, overlap=False):
+        ctx.overlap = overlap
         cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
         with torch.autocast(device_type="cuda", enabled=False):
             xc, wc = x.to(cdt), weight.to(cdt)
@@ -52,23 +55,41 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         xc, wc = ctx.saved_tensors
+        want_w = ctx.needs_input_grad[1]
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+
+        def weight_grads():
+            dw = tall_product(g2, x2, out_dtype=ctx.w_dtype) if want_w else None
+            db = torch.sum(g2, dim=0, dtype=torch.float32) if want_b else None
+            if dw is not None and dw.dtype != ctx.w_dtype:      # bf16 working weights (trainer.MasterWeightAdam)
+                dw = dw.to(ctx.w_dtype)
+            if db is not None and db.dtype != ctx.b_dtype:
+                db = db.to(ctx.b_dtype)
+            return dw, db
+
         with torch.autocast(device_type="cuda", enabled=False):
             g2 = grad.reshape(-1, grad.shape[-1]).to(xc.dtype)
             x2 = xc.reshape(-1, xc.shape[-1])
+            dw = db = None
+            forked = ctx.overlap and (want_w or want_b)
+            if forked:
+                # weight / bias gradients on the side stream (seld_overlap): the main stream goes on with dx
+                with seld_overlap.fork(grad.device, g2, x2) as f:
+                    dw, db = weight_grads()
+                    f.outputs(dw, db)
             dx = (g2 @ wc).view_as(xc) if ctx.needs_input_grad[0] else None
-            dw = tall_product(g2, x2, out_dtype=ctx.w_dtype) if ctx.needs_input_grad[1] else None
-            db = torch.sum(g2, dim=0, dtype=torch.float32) if ctx.has_bias and ctx.needs_input_grad[2] else None
+            if not forked:
+                dw, db = weight_grads()
         if dx is not None and dx.dtype != ctx.in_dtype:
             dx = dx.to(ctx.in_dtype)
-        if dw is not None and dw.dtype != ctx.w_dtype:          # bf16 working weights (trainer.MasterWeightAdam)
-            dw = dw.to(ctx.w_dtype)
-        if db is not None and db.dtype != ctx.b_dtype:
-            db = db.to(ctx.b_dtype)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 class SeldLinear(nn.Linear):
     def forward(self, x):
+        late = self.__dict__.pop("_deferred", None)              # seld_overlap.defer_linear: this forward pass only
         if enabled and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.dim() >= 2:
+            if late is not None and torch.is_grad_enabled():
+                return _Linear.apply(x, late[0], late[1] if len(late) > 1 else None, True)
             return _Linear.apply(x, self.weight, self.bias)
         return super().forward(x)

@@ -92,9 +92,12 @@ def prepare_model_for_device(model, device):
         import model_crnn
         model_crnn._Conv3x3.enabled = bool(getattr(config, "CONV_DGRAD_AS_FORWARD", True)) and \
             os.environ.get("SELD_CONV_AS_FWD", "1") != "0"          # developer switch for A/B runs
-        if getattr(config, "FUSED_DWCONV", False):
+        if os.environ.get("SELD_DWCONV") is None:
             import seld_dwconv
-            seld_dwconv.enabled = True
+            seld_dwconv.enabled = getattr(config, "FUSED_DWCONV", "auto")
+        if os.environ.get("SELD_OVERLAP") is None:
+            import seld_overlap
+            seld_overlap.enabled = bool(getattr(config, "OVERLAP_WEIGHT_GRADS", True))
         for module in model.modules():
             if isinstance(module, SeldGRU) and SeldGRU.fused_enabled:
                 seld_gru.pack_parameters(module)

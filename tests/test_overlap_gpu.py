@@ -1,0 +1,96 @@
+"""Side-stream weight gradients (seld_overlap.py): same numbers as the single-stream order, iteration after
+iteration (a missed stream dependency shows up as a stale or half-written gradient), and the identity node really
+runs after GRU layer 0's backward."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _grads(model, x, overlap, steps=1):
+    import seld_overlap
+    seld_overlap.enabled = overlap
+    out = []
+    for _ in range(steps):
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(7)                                   # same dropout masks
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = model(x)
+        (y.float() ** 2).mean().backward()
+        out.append({k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.fixture()
+def crnn():
+    import trainer
+    was = trainer.config.MODEL_TYPE
+    trainer.config.MODEL_TYPE = "crnn"
+    torch.manual_seed(0)
+    dev = torch.device("cuda:0")
+    model = trainer.prepare_model_for_device(trainer.build_model((18, 36)), dev).train()
+    yield model
+    trainer.config.MODEL_TYPE = was
+    import seld_overlap
+    seld_overlap.enabled = True
+
+
+def test_overlapped_gradients_are_bit_identical(crnn):
+    x = torch.randn(8, 250, 4, 64, device="cuda:0") * 20 - 30
+    base, again = _grads(crnn, x, overlap=False, steps=2)
+    # the library's convolution weight gradients accumulate with atomics: only parameters whose single-stream gradient
+    # reproduces run to run can be held to bit equality (the head and the GRU -- everything the side stream touches)
+    exact = [k for k in base if torch.equal(base[k], again[k])]
+    assert all(k in exact for k in base if k.startswith(("fnn.", "rnn."))), exact
+    runs = _grads(crnn, x, overlap=True, steps=12)
+    for i, g in enumerate(runs):
+        for k in base:
+            if k in exact:
+                assert torch.equal(g[k], base[k]), f"iteration {i}: {k} differs with the side stream"
+            else:
+                scale = base[k].float().abs().max().item() + 1e-12
+                assert (g[k].float() - base[k].float()).abs().max().item() <= 2e-2 * scale, (i, k)
+
+
+def test_side_stream_is_used_and_joined_late(crnn, monkeypatch):
+    import seld_overlap
+    events = []
+    real_backward = seld_overlap._Deferred.backward
+    real_enter = seld_overlap.fork.__enter__
+
+    def spy_backward(ctx, *grads):
+        events.append("join")
+        return real_backward(ctx, *grads)
+
+    def spy_enter(self):
+        events.append("fork")
+        return real_enter(self)
+
+    import seld_gru
+    real_gru_backward = seld_gru.seld_native.gru_backward
+
+    def spy_gru_backward(*args, **kwargs):
+        events.append("recurrence")
+        return real_gru_backward(*args, **kwargs)
+
+    monkeypatch.setattr(seld_gru.seld_native, "gru_backward", spy_gru_backward)
+    monkeypatch.setattr(seld_overlap._Deferred, "backward", staticmethod(spy_backward))
+    monkeypatch.setattr(seld_overlap.fork, "__enter__", spy_enter)
+    x = torch.randn(4, 250, 4, 64, device="cuda:0") * 20 - 30
+    _grads(crnn, x, overlap=True)
+    # the head's two Linears fork, layer 1's recurrence runs beside them, layer 1's weight gradients fork, layer 0's
+    # recurrence runs beside those, and only then do the three identity nodes (2 Linears, GRU layer 1) join
+    assert events == ["fork", "fork", "recurrence", "fork", "recurrence", "join", "join", "join"], events
+
+
+def test_eval_and_no_grad_leave_no_alias_behind(crnn):
+    x = torch.randn(2, 250, 4, 64, device="cuda:0")
+    crnn.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        crnn(x)
+    assert "_deferred" not in crnn.fnn[0].__dict__ and "_deferred" not in crnn.fnn[4].__dict__
+    crnn.train()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        crnn(x)
+    assert "_deferred" not in crnn.fnn[0].__dict__ and "_deferred" not in crnn.fnn[4].__dict__
