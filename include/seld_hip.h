@@ -138,6 +138,12 @@ int seld_scale_by_device_scalar(void* data, int is_bf16, int64_t n, const float*
 int seld_multi_cast(const void* const* src, void* const* dst, const int64_t* lengths, int count, int bf16_to_fp32,
                     void* stream);
 
+/* Hold `stream` for `nanoseconds` (0 .. 1e6) with a one-wavefront kernel that watches the 100 MHz wall clock.
+ * Used at the head of the side stream that carries weight-gradient GEMMs beside a BiGRU recurrence
+ * (seld_gru_backward): the recurrence's 16 workgroups each need a whole CU's LDS and must be resident before the
+ * GEMMs occupy every CU.  No upstream counterpart (the reference's trainer.py:165-179 is single-stream). */
+int seld_stream_delay(int64_t nanoseconds, void* stream);
+
 /* ---- CNN block tail: BatchNorm2d -> ReLU -> MaxPool2d((1,2)) at model_crnn.py:5-17 (ConvBlock.forward) ---- */
 /* x: the convolution output in channels-last memory order = row-major [rows = B*T*F][C] (bf16 when is_bf16, else
  * fp32); the two frequency bins of a pooling pair are adjacent rows.  pool = 2: MaxPool2d((1,2)); pool = 1: no

@@ -76,6 +76,16 @@ __global__ __launch_bounds__(kCastThreads) void multi_cast_kernel(const CastBatc
 
 }  // namespace seld
 
+// A one-wavefront kernel that holds its stream for a given time: seld_overlap puts it at the head of the side stream
+// so that the persistent BiGRU recurrence (16 workgroups that each need a whole CU's LDS) is resident before the
+// weight-gradient GEMMs flood every CU.  Bounded by the constant 100 MHz wall clock: every launch terminates.
+namespace seld {
+__global__ void __launch_bounds__(64) stream_delay_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+}  // namespace seld
+
 extern "C" {
 
 int seld_multi_cast(const void* const* src, void* const* dst, const int64_t* lengths, int count, int bf16_to_fp32,
@@ -103,6 +113,17 @@ int seld_multi_cast(const void* const* src, void* const* dst, const int64_t* len
     if (bf16_to_fp32) hipLaunchKernelGGL(multi_cast_kernel<true>, grid, dim3(kCastThreads), 0, stream, b);
     else hipLaunchKernelGGL(multi_cast_kernel<false>, grid, dim3(kCastThreads), 0, stream, b);
   }
+  SELD_HIP_TRY(hipGetLastError());
+  return kOk;
+}
+
+int seld_stream_delay(int64_t nanoseconds, void* stream_) {
+  using namespace seld;
+  if (!current_state()) return kErrNotInitialised;
+  if (nanoseconds < 0 || nanoseconds > 1000000) return fail(kErrInvalidArgument, "seld_stream_delay: 0 .. 1e6 ns");
+  if (nanoseconds == 0) return kOk;
+  hipLaunchKernelGGL(stream_delay_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream_),
+                     static_cast<long long>(nanoseconds / 10));
   SELD_HIP_TRY(hipGetLastError());
   return kOk;
 }

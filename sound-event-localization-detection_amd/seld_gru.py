@@ -57,13 +57,19 @@ class _BiGRULayer(torch.autograd.Function):
         h = HIDDEN
         n = b * t
         with torch.autocast(device_type="cuda", enabled=False):
-            dgi, dghn, dbias = seld_native.gru_backward(dy.to(y.dtype), saved, y, w_hh)
+            dyc = dy.to(y.dtype)
+            # weight-gradient jobs queued by the layers above start now, beside this recurrence (seld_overlap)
+            seld_overlap.launch_pending(dy.device)
+            dgi, dghn, dbias = seld_native.gru_backward(dyc, saved, y, w_hh)
             dgi2 = dgi.view(n, 6 * h)                                             # d/d(gi), both directions
             x2 = xc.reshape(n, -1)
             t_wih, t_bih, t_whh, t_bhh = ctx.dtypes
 
+            dw_ih = torch.empty((6 * h, x2.shape[1]), dtype=t_wih, device=dy.device)
+            dw_hh = torch.empty((2, 3 * h, h), dtype=t_whh, device=dy.device)
+
             def weight_grads():
-                dw_ih = tall_product(dgi2, x2, out_dtype=t_wih)                  # [6H, In]
+                tall_product(dgi2, x2, out=dw_ih)                                # [6H, In]
                 # h_{t-1} of the forward recurrence: y shifted by one step in each direction's own time order
                 yv = y.view(b, t, 2, h)
                 h_prev = torch.empty_like(yv)
@@ -78,20 +84,16 @@ class _BiGRULayer(torch.autograd.Function):
                 # launches).
                 p_gi = tall_product(dgi2, hp, out_dtype=t_whh).view(2, 3, h, 2, h)   # [dir, gate, unit, dir', unit']
                 p_n = tall_product(dghn.view(n, 2 * h), hp, out_dtype=t_whh).view(2, h, 2, h)
-                dw_hh = torch.empty((2, 3 * h, h), dtype=t_whh, device=dy.device)
                 for d in range(2):
                     dw_hh[d, :2 * h].view(2, h, h).copy_(p_gi[d, :2, :, d])
                     dw_hh[d, 2 * h:].copy_(p_n[d, :, d])
-                return dw_ih, dw_hh
 
-            if ctx.overlap:
-                # side stream (seld_overlap): hidden under the data-gradient GEMM and the NEXT layer's recurrence
-                with seld_overlap.fork(dy.device, dgi, dghn, y, xc) as f:
-                    dw_ih, dw_hh = weight_grads()
-                    f.outputs(dw_ih, dw_hh)
             dx = (dgi2 @ w_ih.to(cdt)).view_as(xc)
-            if not ctx.overlap:
-                dw_ih, dw_hh = weight_grads()
+            if ctx.overlap:
+                # on the side stream, beside the recurrence of the layer below (seld_overlap.launch_pending there)
+                seld_overlap.submit(dy.device, [dgi, dghn, y, xc, dw_ih, dw_hh], weight_grads)
+            else:
+                weight_grads()
             db_ih = dbias[:, :3].reshape(-1)
             db_hh = torch.cat((dbias[:, :2], dbias[:, 3:]), dim=1).reshape(2, 3 * h)
         return dx.to(dy.dtype) if dx.dtype != dy.dtype and not torch.is_autocast_enabled() else dx, \

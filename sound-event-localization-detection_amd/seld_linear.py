@@ -16,13 +16,13 @@ import seld_overlap
 enabled = True
 
 
-def tall_product(a, c, out_dtype=torch.float32):
+def tall_product(a, c, out_dtype=torch.float32, out=None):
     """a^T c for tall operands (a [N, G], c [N, K]) -> [G, K] in ``out_dtype``.  Row strides may be anything (column
     stride 1).  The library's transposed-A GEMM with an 8000-row reduction runs at a fraction of its usual rate, the
     more so the smaller the output (measured, bf16, N = 8000, tools/bench_tall_product.py: 9072 x 512 125 us as one
     GEMM vs 95 us in 5 row chunks; 1536 x 2048 93 vs 76; 512 x 512 52 vs 27 in 8): the rows are split into chunks
     multiplied as ONE batched GEMM on transposed views (no copies) and the partial products are added by a reduction
-    that accumulates in fp32 and writes ``out_dtype`` directly."""
+    that accumulates in fp32 and writes ``out_dtype`` directly (into ``out`` if given)."""
     n, g = a.shape
     k = c.shape[1]
     tiles = ((g + 127) // 128) * ((k + 127) // 128)
@@ -30,10 +30,14 @@ def tall_product(a, c, out_dtype=torch.float32):
     while chunks > 1 and (n % chunks or n // chunks < 256):
         chunks -= 1
     if chunks == 1:
-        out = a.t() @ c
-        return out if out.dtype == out_dtype else out.to(out_dtype)
+        prod = a.t() @ c
+        if out is not None:
+            return out.copy_(prod)
+        return prod if prod.dtype == out_dtype else prod.to(out_dtype)
     av = a.unflatten(0, (chunks, n // chunks)).transpose(1, 2)                    # [chunks, G, N/chunks] view
     cv = c.unflatten(0, (chunks, n // chunks))
+    if out is not None:
+        return torch.sum(torch.bmm(av, cv), dim=0, dtype=out.dtype, out=out)
     return torch.sum(torch.bmm(av, cv), dim=0, dtype=out_dtype)
 
 
@@ -58,28 +62,30 @@ class _Linear(torch.autograd.Function):
         want_w = ctx.needs_input_grad[1]
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
 
-        def weight_grads():
-            dw = tall_product(g2, x2, out_dtype=ctx.w_dtype) if want_w else None
-            db = torch.sum(g2, dim=0, dtype=torch.float32) if want_b else None
-            if dw is not None and dw.dtype != ctx.w_dtype:      # bf16 working weights (trainer.MasterWeightAdam)
-                dw = dw.to(ctx.w_dtype)
-            if db is not None and db.dtype != ctx.b_dtype:
-                db = db.to(ctx.b_dtype)
-            return dw, db
-
         with torch.autocast(device_type="cuda", enabled=False):
             g2 = grad.reshape(-1, grad.shape[-1]).to(xc.dtype)
             x2 = xc.reshape(-1, xc.shape[-1])
-            dw = db = None
-            forked = ctx.overlap and (want_w or want_b)
-            if forked:
-                # weight / bias gradients on the side stream (seld_overlap): the main stream goes on with dx
-                with seld_overlap.fork(grad.device, g2, x2) as f:
-                    dw, db = weight_grads()
-                    f.outputs(dw, db)
             dx = (g2 @ wc).view_as(xc) if ctx.needs_input_grad[0] else None
-            if not forked:
-                dw, db = weight_grads()
+            dw = db = None
+            if ctx.overlap and (want_w or want_b):
+                # side stream, started with the next BiGRU recurrence (seld_overlap): outputs are allocated now
+                if want_w:
+                    dw = torch.empty((g2.shape[1], x2.shape[1]), dtype=ctx.w_dtype, device=grad.device)
+                if want_b:
+                    db = torch.empty((g2.shape[1],), dtype=ctx.b_dtype, device=grad.device)
+
+                def job():
+                    if dw is not None:
+                        tall_product(g2, x2, out=dw)
+                    if db is not None:
+                        db.copy_(torch.sum(g2, dim=0, dtype=torch.float32))
+
+                seld_overlap.submit(grad.device, [t for t in (g2, x2, dw, db) if t is not None], job)
+            else:
+                dw = tall_product(g2, x2, out_dtype=ctx.w_dtype) if want_w else None
+                db = torch.sum(g2, dim=0, dtype=torch.float32) if want_b else None
+                if db is not None and db.dtype != ctx.b_dtype:
+                    db = db.to(ctx.b_dtype)
         if dx is not None and dx.dtype != ctx.in_dtype:
             dx = dx.to(ctx.in_dtype)
         return dx, dw, db, None

@@ -65,6 +65,7 @@ def _declare(lib):
     lib.seld_softmax_mse.argtypes = [_ptr, _int, _ptr, _ptr, _i64, _int, ctypes.c_float, _ptr, _ptr, _ptr, _ptr]
     lib.seld_scale_by_device_scalar.argtypes = [_ptr, _int, _i64, _ptr, _ptr]
     lib.seld_multi_cast.argtypes = [_ptr, _ptr, _ptr, _int, _int, _ptr]
+    lib.seld_stream_delay.argtypes = [_i64, _ptr]
     lib.seld_conv_tail_workspace_floats.restype = _i64
     lib.seld_conv_tail_workspace_floats.argtypes = [_int]
     lib.seld_conv_tail_forward.argtypes = [_ptr, _ptr, _int, _i64, _int, _int, _ptr, _ptr, _ptr, _ptr, ctypes.c_float,
@@ -361,6 +362,12 @@ def scale_by_device_scalar_(data: torch.Tensor, scale: torch.Tensor) -> torch.Te
                                                          _p(scale), _stream_ptr(data.device)),
               "seld_scale_by_device_scalar")
     return data
+
+
+def stream_delay(device, nanoseconds: int) -> None:
+    """Hold the CURRENT stream of ``device`` for ``nanoseconds`` (seld_stream_delay)."""
+    with _device_guard(ensure_init(device)):
+        check(load_library().seld_stream_delay(int(nanoseconds), _stream_ptr(device)), "seld_stream_delay")
 
 
 def _dense_like(a: torch.Tensor, b: torch.Tensor) -> bool:

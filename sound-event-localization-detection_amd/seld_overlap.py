@@ -4,19 +4,25 @@ The backward recurrence of a BiGRU layer (csrc/gru.hip) is a persistent kernel o
 direction and 4-sequence tile at batch 32) for ~365 us, and the chain head -> layer 1 -> layer 0 is serial: the
 other 240 CUs idle.  The WEIGHT gradients of the layers just before it on that chain (the head's Linears, then
 layer 1's dW_ih / dW_hh) are not on the chain: nothing needs them before the optimiser (or DDP's bucket of that
-parameter).  ``SeldLinear`` / ``seld_gru`` enqueue them on a side stream; the main stream goes on with the data
-gradient and the next recurrence.
+parameter).  ``SeldLinear`` / ``seld_gru`` hand them to ``submit`` as jobs with preallocated outputs; the next
+recurrence launch (``launch_pending``, called by ``seld_gru`` right before it enqueues the kernel) puts them on a side
+stream that waits for everything the main stream had enqueued up to that point -- so they start WITH the recurrence
+and fill the idle CUs instead of competing with the data-gradient GEMMs before it (measured: forking at the Linear's
+own backward gained 2 %, forking at the recurrence launch N %).
 
 Ordering without touching the autograd engine: ``defer(...)`` routes the parameters through an identity node that
 is created EARLY in the forward pass (before GRU layer 0), so the engine -- highest sequence number first -- runs
-its backward LATE: after layer 0's recurrence, before the convolution stack.  That node is where the main stream
-waits for the side stream, so everything downstream of it (AccumulateGrad, DDP's reducer hooks and their bucket
-copies / all-reduce, which then overlap the convolution backward) sees finished gradients on the stream it expects.
-If the engine ever ordered it differently the result would still be correct -- only the overlap would be lost.
+its backward LATE: after layer 0's recurrence, before the convolution stack.  That node launches whatever is still
+pending and makes the main stream wait for the side stream, so everything downstream of it (AccumulateGrad, DDP's
+reducer hooks and their bucket copies / all-reduce, which then overlap the convolution backward) sees finished
+gradients on the stream it expects.  If the engine ever ordered it differently the result would still be correct --
+only the overlap would be lost.
 """
 import os
 
 import torch
+
+import seld_native
 
 enabled = os.environ.get("SELD_OVERLAP", "1") != "0"      # Config.OVERLAP_WEIGHT_GRADS via trainer.prepare_model_for_device
 _streams = {}
@@ -33,6 +39,39 @@ def active(x):
     return enabled and x.is_cuda and torch.is_grad_enabled()
 
 
+# The recurrence's 16 workgroups each need a whole CU's LDS: if the GEMMs get to the CUs first the recurrence waits for
+# a CU to drain (tools/bench_overlap.py: recurrence 383 us alone, 473 us beside a 139 us job, 440 us when the job starts
+# 20 us late).  The main stream still has the dy layout converter (~12 us) to run before the recurrence launches.
+head_start_ns = 25000
+
+_pending = []       # (device, tensors, job): weight-gradient jobs waiting for the next recurrence launch (or the join)
+
+
+def submit(device, tensors, job):
+    """Queue ``job()`` (kernels reading / writing ``tensors``, all allocated on the main stream) for the side stream."""
+    _pending.append((device, tensors, job))
+
+
+def launch_pending(device):
+    """Enqueue the queued jobs on the side stream, behind everything the main stream holds right now."""
+    if not _pending:
+        return 0
+    jobs = list(_pending)
+    del _pending[:]
+    main = torch.cuda.current_stream(device)
+    side = side_stream(device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        if head_start_ns:
+            seld_native.stream_delay(device, head_start_ns)
+        for _, _, job in jobs:
+            job()
+    for _, tensors, _ in jobs:
+        for t in tensors:
+            t.record_stream(side)               # main-stream allocations in use on the side stream
+    return len(jobs)
+
+
 class _Deferred(torch.autograd.Function):
     @staticmethod
     def forward(ctx, *params):
@@ -42,12 +81,13 @@ class _Deferred(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, *grads):
+        launch_pending(ctx.device)
         torch.cuda.current_stream(ctx.device).wait_stream(side_stream(ctx.device))
         return grads
 
 
 def defer(*params):
-    """Aliases of ``params`` whose gradients may be produced on the side stream (``fork``)."""
+    """Aliases of ``params`` whose gradients may be produced by ``submit``-ted jobs."""
     return _Deferred.apply(*params)
 
 
@@ -56,32 +96,3 @@ def defer_linear(*modules):
     for m in modules:
         ps = (m.weight,) if m.bias is None else (m.weight, m.bias)
         m.__dict__["_deferred"] = defer(*ps)
-
-
-class fork:
-    """``with fork(device, inputs) as f: ... f.outputs(...)``: run the block on the side stream once the main stream's
-    work enqueued so far is done.  ``inputs`` were allocated on the main stream and are read here, ``outputs`` are
-    allocated here and consumed on the main stream: both are recorded with the caching allocator."""
-
-    def __init__(self, device, *inputs):
-        self.main = torch.cuda.current_stream(device)
-        self.side = side_stream(device)
-        self.inputs = inputs
-        self.ctx = torch.cuda.stream(self.side)
-
-    def __enter__(self):
-        self.side.wait_stream(self.main)
-        self.ctx.__enter__()
-        return self
-
-    def outputs(self, *tensors):
-        for t in tensors:
-            if t is not None:
-                t.record_stream(self.main)
-
-    def __exit__(self, *exc):
-        self.ctx.__exit__(*exc)
-        for t in self.inputs:
-            if t is not None:
-                t.record_stream(self.side)
-        return False

@@ -57,15 +57,17 @@ def test_side_stream_is_used_and_joined_late(crnn, monkeypatch):
     import seld_overlap
     events = []
     real_backward = seld_overlap._Deferred.backward
-    real_enter = seld_overlap.fork.__enter__
+    real_launch = seld_overlap.launch_pending
 
     def spy_backward(ctx, *grads):
         events.append("join")
         return real_backward(ctx, *grads)
 
-    def spy_enter(self):
-        events.append("fork")
-        return real_enter(self)
+    def spy_launch(device):
+        n = real_launch(device)
+        if n:
+            events.append(f"launch {n}")
+        return n
 
     import seld_gru
     real_gru_backward = seld_gru.seld_native.gru_backward
@@ -76,12 +78,13 @@ def test_side_stream_is_used_and_joined_late(crnn, monkeypatch):
 
     monkeypatch.setattr(seld_gru.seld_native, "gru_backward", spy_gru_backward)
     monkeypatch.setattr(seld_overlap._Deferred, "backward", staticmethod(spy_backward))
-    monkeypatch.setattr(seld_overlap.fork, "__enter__", spy_enter)
+    monkeypatch.setattr(seld_overlap, "launch_pending", spy_launch)
     x = torch.randn(4, 250, 4, 64, device="cuda:0") * 20 - 30
     _grads(crnn, x, overlap=True)
-    # the head's two Linears fork, layer 1's recurrence runs beside them, layer 1's weight gradients fork, layer 0's
-    # recurrence runs beside those, and only then do the three identity nodes (2 Linears, GRU layer 1) join
-    assert events == ["fork", "fork", "recurrence", "fork", "recurrence", "join", "join", "join"], events
+    # the head's two Linears queue their weight gradients, which start beside layer 1's recurrence; layer 1's start
+    # beside layer 0's recurrence; only then do the three identity nodes (2 Linears, GRU layer 1) join
+    assert events == ["launch 2", "recurrence", "launch 1", "recurrence", "join", "join", "join"], events
+    assert not seld_overlap._pending
 
 
 def test_eval_and_no_grad_leave_no_alias_behind(crnn):
@@ -94,3 +97,20 @@ def test_eval_and_no_grad_leave_no_alias_behind(crnn):
     with torch.autocast("cuda", dtype=torch.bfloat16):
         crnn(x)
     assert "_deferred" not in crnn.fnn[0].__dict__ and "_deferred" not in crnn.fnn[4].__dict__
+
+
+def test_stream_delay_holds_its_stream_and_only_that():
+    import seld_native
+    dev = torch.device("cuda:0")
+    seld_native.ensure_init(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for ns in (25_000, 400_000):
+        torch.cuda.synchronize()
+        e0.record()
+        seld_native.stream_delay(dev, ns)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3
+        assert ns / 1e3 <= us + 1 and us < ns / 1e3 + 200, (ns, us)
+    with pytest.raises(RuntimeError):
+        seld_native.stream_delay(dev, 2_000_000)              # bounded: nothing can park a stream for long
