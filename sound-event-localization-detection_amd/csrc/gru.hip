@@ -233,8 +233,9 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
     for (int gate = 0; gate < 3; ++gate) g[gate] = p[gate * 64];
   };
 
-  // `g` holds this step's operands on entry; they are unpacked at once and the SAME registers then receive
-  // the next step's operands (a whole step of cover), so no second operand set is needed.
+  // `g` holds this step's operands on entry; they are unpacked at once and the same registers then receive the
+  // operands of the step after the next one (two register sets used alternately: two steps, ~2.4 us, of cover for
+  // every global load -- one step is not enough: HBM answers in about a step's time, later under load).
   auto step = [&](long t, Group<D> (&g)[3]) {
     const long tt = time_of(t);
     const int cur = static_cast<int>(t & 1), nxt = cur ^ 1;
@@ -247,7 +248,7 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
     // otherwise sinks the loads below this step's stores, and the in-order vmcnt then makes the next step
     // wait for those stores' round trip.
     __builtin_amdgcn_sched_barrier(0);
-    load_gi(t + 1 < a.T ? t + 1 : a.T - 1, g);
+    load_gi(t + 2 < a.T ? t + 2 : a.T - 1, g);
     __builtin_amdgcn_sched_barrier(0);
     // ---- gh^T = W_hh h^T : B fragments (k, n = column c) of h_{t-1} and the n-gate A fragments from LDS,
     // read one k-step ahead of the MFMAs that consume them (the LDS latency hides under 6 MFMAs).  The padding
@@ -311,14 +312,20 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
     }
   };
 
-  Group<D> g[3];
-  load_gi(0, g);
+  Group<D> g_a[3], g_b[3];
+  load_gi(0, g_a);
+  load_gi(a.T > 1 ? 1 : 0, g_b);
   // The first step is peeled so that the loop is ENTERED in the same memory-queue state as the back edge
   // leaves it; otherwise the compiler merges the two states conservatively and every step waits for the
   // previous step's stores.
-  step(0, g);
+  step(0, g_a);
+  long t = 1;
 #pragma unroll 1
-  for (long t = 1; t < a.T; ++t) step(t, g);
+  for (; t + 1 < a.T; t += 2) {
+    step(t, g_b);
+    step(t + 1, g_a);
+  }
+  if (t < a.T) step(t, g_b);
 }
 
 template <typename T>
@@ -407,8 +414,10 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
     in.d = dy[tile_group(tile, a.T, tt, dir, wave, 1, 0, lane)];
   };
 
-  // `in` holds this step's operands on entry; they are unpacked at once and the same registers then receive
-  // the operands of the next (earlier-in-time) step.
+  // `in` holds this step's operands on entry; they are unpacked at once and the same registers then receive the
+  // operands of the step after the next one (two register sets, used alternately): every global load has two whole
+  // steps (~3 us) to arrive, so the recurrence keeps its pace when weight-gradient GEMMs run beside it on the other
+  // CUs (seld_overlap.py) and the memory system answers late.
   auto step = [&](long t, GruStepIn<T>& in) {
     const long tt = time_of(t);
     float r[kU], z[kU], n[kU], g[kU], hp[kU], d[kU];
@@ -417,7 +426,7 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
     dec1<D>(in.hp, hp);
     dec1<D>(in.d, d);
     __builtin_amdgcn_sched_barrier(0);
-    load_step(t > 0 ? t - 1 : 0, in);              // unconditional, clamped; pinned ahead of this step's stores
+    load_step(t > 1 ? t - 2 : 0, in);              // unconditional, clamped; pinned ahead of this step's stores
     __builtin_amdgcn_sched_barrier(0);
     float keep[kU], da_r[kU], da_z[kU], da_n[kU], dghn[kU];
 #pragma unroll
@@ -484,12 +493,18 @@ __device__ __forceinline__ void gru_backward_steps(const GruBwdArgs& a, bf16x8* 
     for (int i = 0; i < kU; ++i) dh[i] = keep[i] + mine[i];
   };
 
-  GruStepIn<T> in;
-  load_step(a.T - 1, in);
+  GruStepIn<T> in_a, in_b;
+  load_step(a.T - 1, in_a);
+  load_step(a.T > 1 ? a.T - 2 : 0, in_b);
   // reverse of the forward processing order; first step peeled (see the forward kernel)
-  step(a.T - 1, in);
+  step(a.T - 1, in_a);
+  long t = a.T - 2;
 #pragma unroll 1
-  for (long t = a.T - 2; t >= 0; --t) step(t, in);
+  for (; t >= 1; t -= 2) {
+    step(t, in_b);
+    step(t - 1, in_a);
+  }
+  if (t == 0) step(0, in_b);
 
   // bias gradients: add the kSeqs sequences of the tile (lanes that differ in c % kSeqs), one group per slot
 #pragma unroll
