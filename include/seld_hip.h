@@ -138,6 +138,21 @@ int seld_scale_by_device_scalar(void* data, int is_bf16, int64_t n, const float*
 int seld_multi_cast(const void* const* src, void* const* dst, const int64_t* lengths, int count, int bf16_to_fp32,
                     void* stream);
 
+/* LayerNorm over the last dimension [-> ReLU], activations in their own dtype (csrc/layernorm.hip).  Replaces the
+ * head's nn.LayerNorm(512) -> nn.ReLU of model_crnn.py:77-83 (model_conformer.py / resnet50_model.py: LayerNorm(1024)).
+ * x, y, dy, dx [rows][D] contiguous, fp32 or bf16 (is_bf16); weight, bias [D] fp32; statistics and arithmetic in fp32
+ * (biased two-pass variance, eps inside the square root: torch.nn.functional.layer_norm).  D in {256, 512, 1024, 2048}
+ * (seld_layernorm_supported).  forward writes mean_rstd [rows][2] fp32 -- with x, all the backward pass needs (the
+ * ReLU mask is recomputed).  backward writes dx, dweight [D], dbias [D] (fp32, deterministic two-level sums);
+ * workspace: seld_layernorm_workspace_floats(rows, D) floats. */
+int seld_layernorm_supported(int64_t D);
+int64_t seld_layernorm_workspace_floats(int64_t rows, int64_t D);
+int seld_layernorm_forward(const void* x, int is_bf16, int64_t rows, int64_t D, const float* weight, const float* bias,
+                           float eps, int relu, void* y, float* mean_rstd, void* stream);
+int seld_layernorm_backward(const void* x, const void* dy, int is_bf16, int64_t rows, int64_t D, const float* weight,
+                            const float* bias, const float* mean_rstd, int relu, void* dx, float* dweight,
+                            float* dbias, float* workspace, void* stream);
+
 /* Hold `stream` for `nanoseconds` (0 .. 1e6) with a one-wavefront kernel that watches the 100 MHz wall clock.
  * Used at the head of the side stream that carries weight-gradient GEMMs beside a BiGRU recurrence
  * (seld_gru_backward): the recurrence's 16 workgroups each need a whole CU's LDS and must be resident before the
@@ -220,6 +235,12 @@ int seld_gru_backward(const void* dy_tile, const void* saved_tile, const void* y
 int seld_gru_to_tile(const void* src, int elem_bytes, int64_t B, int64_t T, int ns, void* dst, void* stream);
 int seld_gru_from_pair_tile(const void* dg_tile, int elem_bytes, int64_t B, int64_t T, void* dgi, void* dghn,
                             void* stream);
+
+/* h_{t-1} of the forward recurrence, natural layout: y [B][T][2][H] (the forward output, h_t) ->
+ * h_prev[b][t][0] = y[b][t-1][0], h_prev[b][t][1] = y[b][t+1][1], zero at each direction's first step.  The operand of
+ * the recurrent weight gradient dW_hh = sum_t dgh_t^T h_{t-1} (what autograd through model_crnn.py:65-72's nn.GRU
+ * accumulates step by step). */
+int seld_gru_previous_state(const void* y, int elem_bytes, int64_t B, int64_t T, void* h_prev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -617,6 +617,21 @@ __global__ __launch_bounds__(256) void gru_from_pair_tile_kernel(const Raw<2 * k
   }
 }
 
+// h_{t-1} of the forward recurrence for every (sequence, t, direction): y shifted by one step in each direction's
+// own time order, zero at the first step.  out[b][t][0] = y[b][t-1][0], out[b][t][1] = y[b][t+1][1].  One 16-byte
+// piece per thread; replaces four strided framework copies and two fills per layer and iteration.
+__global__ __launch_bounds__(256) void gru_previous_state_kernel(const uint4* __restrict__ y, long rows, long T,
+                                                                 int pieces, uint4* __restrict__ out) {
+  const long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;      // piece index in [rows][2][pieces]
+  if (i >= rows * 2 * pieces) return;
+  const long row = i / (2 * pieces);
+  const int dir = static_cast<int>((i / pieces) & 1);
+  const long t = row % T;
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (dir == 0 ? t > 0 : t + 1 < T) v = y[dir == 0 ? i - 2 * pieces : i + 2 * pieces];
+  out[i] = v;
+}
+
 }  // namespace seld
 
 extern "C" {
@@ -656,6 +671,21 @@ int seld_gru_from_pair_tile(const void* dg_tile, int elem_bytes, int64_t B, int6
   else hipLaunchKernelGGL(gru_from_pair_tile_kernel<4 * kU>, grid, dim3(256), 0, stream,
                           static_cast<const Raw<8 * kU>*>(dg_tile), static_cast<long>(B), static_cast<long>(T),
                           static_cast<Raw<4 * kU>*>(dgi), static_cast<Raw<4 * kU>*>(dghn));
+  SELD_HIP_TRY(hipGetLastError());
+  return kOk;
+}
+
+int seld_gru_previous_state(const void* y, int elem_bytes, int64_t B, int64_t T, void* h_prev, void* stream_) {
+  using namespace seld;
+  if (!current_state()) return kErrNotInitialised;
+  if (B <= 0 || T <= 0) return fail(kErrInvalidArgument, "seld_gru_previous_state: B and T must be positive");
+  if (elem_bytes != 2 && elem_bytes != 4) return fail(kErrUnsupported, "seld_gru_previous_state: 2- or 4-byte elements");
+  if (!y || !h_prev) return fail(kErrInvalidArgument, "seld_gru_previous_state: null pointer");
+  const int pieces = kH * elem_bytes / 16;
+  const long total = static_cast<long>(B) * T * 2 * pieces;
+  hipLaunchKernelGGL(gru_previous_state_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), static_cast<const uint4*>(y), static_cast<long>(B) * T,
+                     static_cast<long>(T), pieces, static_cast<uint4*>(h_prev));
   SELD_HIP_TRY(hipGetLastError());
   return kOk;
 }

@@ -11,6 +11,7 @@ model_conformer.py:58-62.
 import torch
 import torch.nn as nn
 
+from seld_layernorm import run_head
 from seld_linear import SeldLinear
 import torch.nn.functional as F
 
@@ -138,4 +139,4 @@ class SELD_Conformer(nn.Module):
         y = self.proj(run_cnn_encoder(self.cnn_blocks, x))
         for block in self.conformer_blocks:
             y = block(y)
-        return self.fnn(y).view(batch, frames, self.grid_cells, self.num_classes)
+        return run_head(self.fnn, y).view(batch, frames, self.grid_cells, self.num_classes)

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from seld_layernorm import run_head
 from seld_linear import SeldLinear
 from seld_rnn import SeldGRU
 
@@ -153,7 +154,7 @@ class SELD_CRNN(nn.Module):
                     seld_overlap.defer_linear(self.fnn[0], self.fnn[4])
                 feats, _ = seld_gru.bigru_forward(self.rnn, feats_fc, feature_cf=(y.shape[1], y.shape[3]),
                                                   overlap=overlap)
-                return self.fnn(feats).view(batch, frames, self.grid_cells, self.num_classes)
+                return run_head(self.fnn, feats).view(batch, frames, self.grid_cells, self.num_classes)
         feats = y.permute(0, 2, 1, 3).reshape(batch, frames, -1)                # (channel, frequency) order
         feats, _ = self.rnn(feats)
-        return self.fnn(feats).view(batch, frames, self.grid_cells, self.num_classes)
+        return run_head(self.fnn, feats).view(batch, frames, self.grid_cells, self.num_classes)

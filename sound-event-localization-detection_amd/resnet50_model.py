@@ -9,6 +9,7 @@ The encoder is the torchvision ResNet-50 layout ([3, 4, 6, 3] bottlenecks, expan
 import torch
 import torch.nn as nn
 
+from seld_layernorm import run_head
 from seld_linear import SeldLinear
 
 from model_conformer import ConformerBlock
@@ -121,4 +122,4 @@ class SELD_ResNet50_Conformer(nn.Module):
         y = self.dropout(self.proj(y))
         for block in self.conformer_blocks:
             y = block(y)
-        return self.head(y).view(batch, frames, self.grid_cells, self.num_classes)
+        return run_head(self.head, y).view(batch, frames, self.grid_cells, self.num_classes)

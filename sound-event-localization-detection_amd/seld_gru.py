@@ -71,13 +71,7 @@ class _BiGRULayer(torch.autograd.Function):
             def weight_grads():
                 tall_product(dgi2, x2, out=dw_ih)                                # [6H, In]
                 # h_{t-1} of the forward recurrence: y shifted by one step in each direction's own time order
-                yv = y.view(b, t, 2, h)
-                h_prev = torch.empty_like(yv)
-                h_prev[:, 1:, 0] = yv[:, :-1, 0]
-                h_prev[:, :-1, 1] = yv[:, 1:, 1]
-                h_prev[:, 0, 0] = 0
-                h_prev[:, -1, 1] = 0
-                hp = h_prev.view(n, 2 * h)
+                hp = seld_native.gru_previous_state(y).view(n, 2 * h)
                 # d/d(gh) = (da_r, da_z, da_n * r).  Two well-shaped products instead of eight skinny ones: all of
                 # dgi and dghn against both directions' h_prev; the wanted blocks are those with matching directions
                 # (the cross-direction blocks and dgi's n rows are computed and dropped: ~6 GFLOP, cheaper than the

@@ -66,6 +66,12 @@ def _declare(lib):
     lib.seld_scale_by_device_scalar.argtypes = [_ptr, _int, _i64, _ptr, _ptr]
     lib.seld_multi_cast.argtypes = [_ptr, _ptr, _ptr, _int, _int, _ptr]
     lib.seld_stream_delay.argtypes = [_i64, _ptr]
+    lib.seld_layernorm_supported.argtypes = [_i64]
+    lib.seld_layernorm_workspace_floats.restype = _i64
+    lib.seld_layernorm_workspace_floats.argtypes = [_i64, _i64]
+    lib.seld_layernorm_forward.argtypes = [_ptr, _int, _i64, _i64, _ptr, _ptr, ctypes.c_float, _int, _ptr, _ptr, _ptr]
+    lib.seld_layernorm_backward.argtypes = [_ptr, _ptr, _int, _i64, _i64, _ptr, _ptr, _ptr, _int, _ptr, _ptr, _ptr,
+                                            _ptr, _ptr]
     lib.seld_conv_tail_workspace_floats.restype = _i64
     lib.seld_conv_tail_workspace_floats.argtypes = [_int]
     lib.seld_conv_tail_forward.argtypes = [_ptr, _ptr, _int, _i64, _int, _int, _ptr, _ptr, _ptr, _ptr, ctypes.c_float,
@@ -76,6 +82,7 @@ def _declare(lib):
     lib.seld_dwconv1d_wgrad.argtypes = [_ptr, _ptr, _int, _i64, _i64, _int, _int, _ptr, _ptr]
     lib.seld_gru_to_tile.argtypes = [_ptr, _int, _i64, _i64, _int, _ptr, _ptr]
     lib.seld_gru_from_pair_tile.argtypes = [_ptr, _int, _i64, _i64, _ptr, _ptr, _ptr]
+    lib.seld_gru_previous_state.argtypes = [_ptr, _int, _i64, _i64, _ptr, _ptr]
     lib.seld_gru_tile_rows.restype = _i64
     lib.seld_gru_tile_rows.argtypes = []
     lib.seld_gru_forward.argtypes = [_ptr, _int, _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr]
@@ -364,6 +371,40 @@ def scale_by_device_scalar_(data: torch.Tensor, scale: torch.Tensor) -> torch.Te
     return data
 
 
+def layernorm_supported(d: int) -> bool:
+    return bool(load_library().seld_layernorm_supported(int(d)))
+
+
+def layernorm_forward(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float, relu: bool):
+    """x [..., D] contiguous fp32 / bf16; weight, bias [D] fp32 -> (y like x, mean_rstd [rows, 2] fp32)."""
+    d = x.shape[-1]
+    rows = x.numel() // d
+    y = torch.empty_like(x)
+    stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    with _device_guard(ensure_init(x.device)):
+        check(load_library().seld_layernorm_forward(_p(x), int(x.dtype == torch.bfloat16), rows, d, _p(weight), _p(bias),
+                                                    float(eps), int(relu), _p(y), _p(stats), _stream_ptr(x.device)),
+              "seld_layernorm_forward")
+    return y, stats
+
+
+def layernorm_backward(x: torch.Tensor, dy: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
+                       stats: torch.Tensor, relu: bool):
+    """-> (dx like x, dweight [D] fp32, dbias [D] fp32)."""
+    d = x.shape[-1]
+    rows = x.numel() // d
+    lib = load_library()
+    dx = torch.empty_like(x)
+    dweight = torch.empty((d,), dtype=torch.float32, device=x.device)
+    dbias = torch.empty((d,), dtype=torch.float32, device=x.device)
+    work = torch.empty((lib.seld_layernorm_workspace_floats(rows, d),), dtype=torch.float32, device=x.device)
+    with _device_guard(ensure_init(x.device)):
+        check(lib.seld_layernorm_backward(_p(x), _p(dy), int(x.dtype == torch.bfloat16), rows, d, _p(weight), _p(bias),
+                                          _p(stats), int(relu), _p(dx), _p(dweight), _p(dbias), _p(work),
+                                          _stream_ptr(x.device)), "seld_layernorm_backward")
+    return dx, dweight, dbias
+
+
 def stream_delay(device, nanoseconds: int) -> None:
     """Hold the CURRENT stream of ``device`` for ``nanoseconds`` (seld_stream_delay)."""
     with _device_guard(ensure_init(device)):
@@ -568,6 +609,18 @@ def from_pair_tile_device(x: torch.Tensor, batch: int):
         check(load_library().seld_gru_from_pair_tile(_p(x), x.element_size(), batch, t, _p(dgi), _p(dghn),
                                                      _stream_ptr(x.device)), "seld_gru_from_pair_tile")
     return dgi, dghn
+
+
+def gru_previous_state(y: torch.Tensor) -> torch.Tensor:
+    """y [B, T, 2*256] (h_t of both directions) -> h_{t-1} in each direction's own time order, same shape; zero at the
+    first step (t = 0 forward, t = T-1 reverse)."""
+    b, t, _ = y.shape
+    y = y.contiguous()
+    out = torch.empty_like(y)
+    with _device_guard(ensure_init(y.device)):
+        check(load_library().seld_gru_previous_state(_p(y), y.element_size(), b, t, _p(out), _stream_ptr(y.device)),
+              "seld_gru_previous_state")
+    return out
 
 
 def gru_forward(gi: torch.Tensor, w_hh: torch.Tensor, b_hn: torch.Tensor, need_saved: bool):

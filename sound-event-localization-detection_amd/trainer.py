@@ -95,6 +95,9 @@ def prepare_model_for_device(model, device):
         if os.environ.get("SELD_DWCONV") is None:
             import seld_dwconv
             seld_dwconv.enabled = getattr(config, "FUSED_DWCONV", "auto")
+        import seld_layernorm
+        seld_layernorm.enabled = bool(getattr(config, "FUSED_LAYERNORM", True)) and \
+            os.environ.get("SELD_LAYERNORM", "1") != "0"            # developer switch for A/B runs
         if os.environ.get("SELD_OVERLAP") is None:
             import seld_overlap
             seld_overlap.enabled = bool(getattr(config, "OVERLAP_WEIGHT_GRADS", True))

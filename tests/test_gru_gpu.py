@@ -108,3 +108,18 @@ def test_layout_converters_match_the_torch_permutes(gpu_device, batch, steps, ns
     dgi, dghn = seld_native.from_pair_tile_device(dg, batch)
     ref_gi, ref_n = seld_native.from_pair_tile(dg, batch)
     assert torch.equal(dgi, ref_gi) and torch.equal(dghn, ref_n)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", [(3, 5), (1, 1), (32, 250), (7, 2)])
+def test_previous_state_is_y_shifted_in_each_directions_time_order(dtype, shape):
+    import seld_native
+    b, t = shape
+    torch.manual_seed(b * 1000 + t)
+    y = torch.randn(b, t, 512, device="cuda:0").to(dtype)
+    got = seld_native.gru_previous_state(y)
+    yv = y.view(b, t, 2, 256)
+    want = torch.zeros_like(yv)
+    want[:, 1:, 0] = yv[:, :-1, 0]
+    want[:, :-1, 1] = yv[:, 1:, 1]
+    assert torch.equal(got.view(b, t, 2, 256), want)
