@@ -224,6 +224,15 @@ def kernel_rooflines(device):
     mask = torch.zeros(BATCH, WINDOW, 648, dtype=torch.uint16, device=device)
     hbm("seld::softmax_mse_kernel (loss + gradient)", 2 * logits.numel() * 2 + mask.numel() * 2,
         timeit(lambda: nat.softmax_mse(logits, mask, grad_scale=1.0)))
+    # head LayerNorm(512) -> ReLU (csrc/layernorm.hip): bf16 x read + y written; backward x, dy read + dx written
+    xl = torch.randn(BATCH * WINDOW, 512, device=device).to(torch.bfloat16)
+    lw, lb = torch.ones(512, device=device), torch.zeros(512, device=device)
+    yl, st = nat.layernorm_forward(xl, lw, lb, 1e-5, True)
+    gl = torch.randn_like(xl)
+    hbm("seld::layernorm_forward_kernel (LayerNorm+ReLU, D=512)", 2 * xl.numel() * 2,
+        timeit(lambda: nat.layernorm_forward(xl, lw, lb, 1e-5, True)))
+    hbm("seld::layernorm_backward_kernel (+ column-sum reduction, D=512)", 3 * xl.numel() * 2,
+        timeit(lambda: nat.layernorm_backward(xl, gl, lw, lb, st, True)))
     # label mask expansion and window gather (csrc/labels.hip)
     starts = torch.arange(0, BATCH * HOP, HOP, dtype=torch.int64, device=device)
     tm = torch.zeros(BATCH * HOP + WINDOW, 648, dtype=torch.uint16, device=device)

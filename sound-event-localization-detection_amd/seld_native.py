@@ -420,13 +420,25 @@ def _dense_like(a: torch.Tensor, b: torch.Tensor) -> bool:
     return a.is_contiguous() or (a.dim() == 4 and a.is_contiguous(memory_format=torch.channels_last))
 
 
-def multi_cast(srcs, dsts) -> bool:
+def multi_cast(srcs, dsts, cache=None) -> bool:
     """dsts[i] <- srcs[i] for lists of GPU tensors, bf16 -> fp32 or fp32 -> bf16 (all pairs the same direction), in one
     launch per 96 tensors (csrc/cast.hip).  Returns False -- having done nothing -- when a pair does not share its
-    memory layout, so that the caller can fall back to the framework's copies."""
+    memory layout, so that the caller can fall back to the framework's copies.  ``cache``: a dict owned by a caller
+    that passes the SAME parameter lists every iteration (the optimiser): the layout checks and the descriptor arrays
+    are reused while every address is unchanged (the step is enqueue-bound: this is ~80 us of host time per call)."""
     srcs, dsts = list(srcs), list(dsts)
     if not srcs:
         return True
+    if cache is not None:
+        key = tuple(t.data_ptr() for t in srcs) + tuple(t.data_ptr() for t in dsts)
+        hit = cache.get("key") == key
+        if hit:
+            src, dst, lengths, n, to_float = cache["args"]
+            device = srcs[0].device
+            with _device_guard(ensure_init(device)):
+                check(load_library().seld_multi_cast(src, dst, lengths, n, to_float, _stream_ptr(device)),
+                      "seld_multi_cast")
+            return True
     to_float = srcs[0].dtype == torch.bfloat16
     want = (torch.bfloat16, torch.float32) if to_float else (torch.float32, torch.bfloat16)
     for s, d in zip(srcs, dsts):
@@ -437,6 +449,8 @@ def multi_cast(srcs, dsts) -> bool:
     dst = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts])
     lengths = (ctypes.c_int64 * n)(*[s.numel() for s in srcs])
     device = srcs[0].device
+    if cache is not None:
+        cache["key"], cache["args"] = key, (src, dst, lengths, n, int(to_float))
     with _device_guard(ensure_init(device)):
         check(load_library().seld_multi_cast(src, dst, lengths, n, int(to_float), _stream_ptr(device)), "seld_multi_cast")
     return True

@@ -333,6 +333,7 @@ class MasterWeightAdam(torch.optim.Adam):
         super().__init__(list(masters) + list(others), **kwargs)
         self._low, self._masters, self._others = list(low), list(masters), list(others)
         self.fused_casts = self.fallback_casts = 0        # how often the one-launch casts applied (diagnostics)
+        self._grad_cast_cache, self._weight_cast_cache = {}, {}
         for m in self._masters:
             m.grad = torch.zeros_like(m)
 
@@ -341,7 +342,7 @@ class MasterWeightAdam(torch.optim.Adam):
         import seld_native
         grads = [p.grad for p in self._low]
         master_grads = [m.grad for m in self._masters]
-        if all(g is not None for g in grads) and seld_native.multi_cast(grads, master_grads):
+        if all(g is not None for g in grads) and seld_native.multi_cast(grads, master_grads, self._grad_cast_cache):
             self.fused_casts += 1
         else:
             self.fallback_casts += 1
@@ -349,7 +350,7 @@ class MasterWeightAdam(torch.optim.Adam):
                 m.grad.zero_() if g is None else m.grad.copy_(g)
         out = super().step(closure)
         working = [p.data for p in self._low]
-        if not seld_native.multi_cast(self._masters, working):
+        if not seld_native.multi_cast(self._masters, working, self._weight_cast_cache):
             torch._foreach_copy_(working, self._masters)
         return out
 

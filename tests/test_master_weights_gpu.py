@@ -70,3 +70,21 @@ def test_multi_cast_matches_torch(gpu_device):
     # layout mismatch: refused, nothing written
     bad = torch.zeros(64, 4, 3, 3, device=gpu_device, dtype=torch.bfloat16)             # NCHW vs channels-last source
     assert not seld_native.multi_cast([src[1]], [bad]) and bad.abs().sum().item() == 0
+
+
+def test_multi_cast_descriptor_cache_follows_the_addresses(gpu_device):
+    import seld_native
+    g = torch.Generator().manual_seed(1)
+    src = [torch.randn(33, 7, generator=g).to(gpu_device), torch.randn(5, generator=g).to(gpu_device)]
+    low = [torch.empty_like(s, dtype=torch.bfloat16) for s in src]
+    cache = {}
+    for _ in range(3):                                                   # miss, then hits
+        src[0].add_(1.0)
+        assert seld_native.multi_cast(src, low, cache)
+        assert all(torch.equal(a.to(torch.bfloat16), b) for a, b in zip(src, low))
+    first_key = cache["key"]
+    src[1] = torch.randn(5, generator=g).to(gpu_device)                  # a new tensor at a new address: re-validated
+    assert seld_native.multi_cast(src, low, cache) and cache["key"] != first_key
+    assert all(torch.equal(a.to(torch.bfloat16), b) for a, b in zip(src, low))
+    src[1] = torch.randn(5, generator=g).to(gpu_device).double()        # wrong dtype: refused even with a cache
+    assert not seld_native.multi_cast(src, low, cache)
