@@ -196,6 +196,10 @@ def kernel_rooflines(device):
             fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # hold the stream (3 x 1 ms, seld_stream_delay) while the host enqueues the repetitions: the events then
+        # bracket back-to-back kernels, not the ~40 us of Python / ctypes time per call that exceeds the small ones
+        for _ in range(3):
+            nat.stream_delay(device, 1_000_000)
         e0.record()
         for _ in range(reps):
             fn()

@@ -11,7 +11,8 @@
 // statistics and the apply phase; kChunks x V = D / 64 in {4, 8, 16, 32} (D = 256, 512, 1024, 2048).
 // The backward kernel walks rows with a grid-sized stride so that each wavefront keeps running column sums of
 // d(weight), d(bias) in registers; the 4 wavefronts of a block add theirs through LDS and write one partial row per
-// block, a second kernel adds the partial rows in a fixed order (deterministic, no atomics).
+// block, a second kernel adds the partial rows in a fixed order (deterministic, no atomics; all loads of a thread in
+// flight at once: a serial walk over 512 partial rows cost 42 us, more than everything this file replaces).
 #include <hip/hip_bf16.h>
 
 #include "seld_common.h"
@@ -206,25 +207,39 @@ __global__ __launch_bounds__(64 * kLnWaves) void layernorm_backward_kernel(const
   }
 }
 
-// out[0][col] = sum over blocks of partial[blk][0][col] (d weight), out[1][col] likewise (d bias); four column
-// accumulators per thread keep the dependent-add chain short
-__global__ __launch_bounds__(256) void layernorm_backward_final_kernel(const float* __restrict__ partial, int blocks,
-                                                                       int d, float* __restrict__ dweight,
-                                                                       float* __restrict__ dbias) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= 2 * d) return;
-  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-  int k = 0;
-  for (; k + 4 <= blocks; k += 4) {
-    a0 += partial[static_cast<long>(k) * 2 * d + col];
-    a1 += partial[static_cast<long>(k + 1) * 2 * d + col];
-    a2 += partial[static_cast<long>(k + 2) * 2 * d + col];
-    a3 += partial[static_cast<long>(k + 3) * 2 * d + col];
+// out[0][col] = sum over blocks of partial[blk][0][col] (d weight), out[1][col] likewise (d bias).  One block per 64
+// columns: 16 row groups x 64 columns, every thread issues all of its (<= 32) loads before the first add -- one memory
+// round trip instead of a dependent chain over the partial rows -- and the row groups are added through LDS in a fixed
+// order (deterministic).
+constexpr int kFinalGroups = 16;
+constexpr int kFinalPerThread = kLnMaxBlocks / kFinalGroups;
+
+__global__ __launch_bounds__(64 * kFinalGroups) void layernorm_backward_final_kernel(const float* __restrict__ partial,
+                                                                                    int blocks, int d,
+                                                                                    float* __restrict__ dweight,
+                                                                                    float* __restrict__ dbias) {
+  __shared__ float fold[kFinalGroups][64];
+  const int lane = threadIdx.x & 63, group = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;                       // < 2 * d (d is a multiple of 64)
+  float v[kFinalPerThread];
+#pragma unroll
+  for (int k = 0; k < kFinalPerThread; ++k) {
+    const int row = group + kFinalGroups * k;
+    v[k] = row < blocks ? partial[static_cast<long>(row) * 2 * d + col] : 0.0f;
   }
-  for (; k < blocks; ++k) a0 += partial[static_cast<long>(k) * 2 * d + col];
-  const float total = (a0 + a1) + (a2 + a3);
-  if (col < d) dweight[col] = total;
-  else dbias[col - d] = total;
+#pragma unroll
+  for (int width = kFinalPerThread / 2; width >= 1; width >>= 1)
+#pragma unroll
+    for (int k = 0; k < width; ++k) v[k] += v[k + width];
+  fold[group][lane] = v[0];
+  __syncthreads();
+  if (group == 0) {
+    float total = 0.0f;
+#pragma unroll
+    for (int g = 0; g < kFinalGroups; ++g) total += fold[g][lane];
+    if (col < d) dweight[col] = total;
+    else dbias[col - d] = total;
+  }
 }
 
 int backward_blocks(long rows) {
@@ -311,7 +326,7 @@ int seld_layernorm_backward(const void* x, const void* dy, int is_bf16, int64_t 
   if (is_bf16) { SELD_LN_BWD(__hip_bfloat16) } else { SELD_LN_BWD(float) }
 #undef SELD_LN_BWD
   const int d = static_cast<int>(D);
-  hipLaunchKernelGGL(layernorm_backward_final_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, stream, workspace,
+  hipLaunchKernelGGL(layernorm_backward_final_kernel, dim3(2 * d / 64), dim3(64 * kFinalGroups), 0, stream, workspace,
                      backward_blocks(rows), d, dweight, dbias);
   SELD_HIP_TRY(hipGetLastError());
   return kOk;

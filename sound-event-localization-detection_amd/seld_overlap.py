@@ -8,7 +8,7 @@ parameter).  ``SeldLinear`` / ``seld_gru`` hand them to ``submit`` as jobs with 
 recurrence launch (``launch_pending``, called by ``seld_gru`` right before it enqueues the kernel) puts them on a side
 stream that waits for everything the main stream had enqueued up to that point -- so they start WITH the recurrence
 and fill the idle CUs instead of competing with the data-gradient GEMMs before it (measured: forking at the Linear's
-own backward gained 2 %, forking at the recurrence launch N %).
+own backward gained 2 %, forking at the recurrence launch 4 %).
 
 Ordering without touching the autograd engine: ``defer(...)`` routes the parameters through an identity node that
 is created EARLY in the forward pass (before GRU layer 0), so the engine -- highest sequence number first -- runs
@@ -88,6 +88,7 @@ class _Deferred(torch.autograd.Function):
 
 def defer(*params):
     """Aliases of ``params`` whose gradients may be produced by ``submit``-ted jobs."""
+    del _pending[:]           # jobs of a backward pass that was abandoned by an exception: their graph is gone
     return _Deferred.apply(*params)
 
 

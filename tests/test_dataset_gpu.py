@@ -105,6 +105,17 @@ def test_main_py_call_sequence(gpu_device, clips, tmp_path):
     import dataset
     import trainer
     cfg = trainer.config
+    names = ("MODEL_TYPE", "CRNN_CNN_CHANNELS", "CRNN_RNN_HIDDEN", "NUM_EPOCHS", "BATCH_SIZE", "SEED", "OUTPUT_PATH",
+             "CHECKPOINT_PATH", "DEVICE_FEED")
+    saved = {k: getattr(cfg, k) for k in names}
+    try:
+        _main_py_call_sequence(cfg, dataset, trainer, clips, tmp_path)
+    finally:                                   # the config object is shared by every test of the session
+        for k, v in saved.items():
+            setattr(cfg, k, v)
+
+
+def _main_py_call_sequence(cfg, dataset, trainer, clips, tmp_path):
     cfg.MODEL_TYPE, cfg.CRNN_CNN_CHANNELS, cfg.CRNN_RNN_HIDDEN = "crnn", [8, 8, 16, 16], 16
     cfg.NUM_EPOCHS, cfg.BATCH_SIZE, cfg.SEED = 2, 4, 0
     cfg.OUTPUT_PATH, cfg.CHECKPOINT_PATH = tmp_path / "outputs", tmp_path / "checkpoints"

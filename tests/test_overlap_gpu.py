@@ -25,13 +25,14 @@ def _grads(model, x, overlap, steps=1):
 @pytest.fixture()
 def crnn():
     import trainer
-    was = trainer.config.MODEL_TYPE
-    trainer.config.MODEL_TYPE = "crnn"
+    cfg = trainer.config
+    was = (cfg.MODEL_TYPE, cfg.CRNN_CNN_CHANNELS, cfg.CRNN_RNN_HIDDEN, cfg.FUSED_GRU)
+    cfg.MODEL_TYPE, cfg.CRNN_CNN_CHANNELS, cfg.CRNN_RNN_HIDDEN, cfg.FUSED_GRU = "crnn", [64, 128, 256, 512], 256, True
     torch.manual_seed(0)
     dev = torch.device("cuda:0")
     model = trainer.prepare_model_for_device(trainer.build_model((18, 36)), dev).train()
     yield model
-    trainer.config.MODEL_TYPE = was
+    cfg.MODEL_TYPE, cfg.CRNN_CNN_CHANNELS, cfg.CRNN_RNN_HIDDEN, cfg.FUSED_GRU = was
     import seld_overlap
     seld_overlap.enabled = True
 
