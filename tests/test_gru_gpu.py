@@ -44,18 +44,20 @@ def test_forward_matches_bf16_aware_oracle(gpu_device, batch, steps):
     assert (y.cpu() - exact).abs().max().item() <= 3e-2          # bf16 drift of the recurrence
 
 
-def test_module_forward_and_backward(gpu_device):
-    """SeldGRU (nn.GRU parameters, HIP recurrence) against the oracle's autograd, one layer."""
+@pytest.mark.parametrize("batch,steps", [(6, 40), (6, 41), (3, 1), (5, 2), (2, 3), (9, 5)])
+def test_module_forward_and_backward(gpu_device, batch, steps):
+    """SeldGRU (nn.GRU parameters, HIP recurrence) against the oracle's autograd, one layer.  The kernels walk two
+    steps per loop iteration (two operand register sets): even, odd and tiny step counts take different exits."""
     import seld_gru
     from seld_rnn import SeldGRU
     torch.manual_seed(5)
     m = SeldGRU(input_size=96, hidden_size=H, num_layers=1, batch_first=True, bidirectional=True).to(gpu_device)
-    x = torch.randn(6, 40, 96, device=gpu_device, requires_grad=True)
+    x = torch.randn(batch, steps, 96, device=gpu_device, requires_grad=True)
     assert not seld_gru.applicable(m, x)            # fp32 without autocast keeps the stock fp32 nn.GRU ...
     m.allow_fp32 = True                             # ... unless opted in (fp32 build of the kernel, bf16 MFMA operands)
     assert seld_gru.applicable(m, x)
     y, h_n = m(x)
-    assert tuple(y.shape) == (6, 40, 2 * H) and tuple(h_n.shape) == (2, 6, H)
+    assert tuple(y.shape) == (batch, steps, 2 * H) and tuple(h_n.shape) == (2, batch, H)
     go = torch.randn_like(y)
     (y * go).sum().backward()
 
