@@ -193,8 +193,8 @@ int seld_dwconv1d_wgrad(const void* x, const void* dy, int is_bf16, int64_t B, i
 
 /* ---- recurrence: nn.GRU(2048, 256, num_layers=2, bidirectional) at model_crnn.py:65-72 ------- */
 /* One bidirectional GRU layer's recurrence, all T steps in one launch (both directions), H = 256.
- * The batch is processed in tiles of S = seld_gru_tile_rows() sequences (4 in this build; pad B up to a whole
- * tile): one workgroup per (tile, direction); the other columns of each 16-column MFMA are padding so that the
+ * The batch is processed in tiles of S = seld_gru_tile_rows() sequences (4 in this build; tiles = ceil(B / S)):
+ * one workgroup per (tile, direction); the other columns of each 16-column MFMA are padding so that the
  * per-CU vector-memory and gate-math work of a step -- what bounds it once the weights are resident -- is
  * spread over more CUs.
  *
@@ -203,18 +203,20 @@ int seld_dwconv1d_wgrad(const void* x, const void* dy, int is_bf16, int64_t B, i
  * X[b][t][dir][slot][u] (b = S*tile + seq, u = 32*w + 16*s + 4*q + i, 4*s + i = U*part + j) is stored as
  * [tile][t][dir][w(8)][slot(NS)][q(4)][part(P)][seq(S)][j(U)]  (seld_gru_to_tile / seld_gru_from_pair_tile
  * convert; seld_native.to_tile / from_tile are their torch definitions).
- *   gi_tile    NS=3  input projections x W_ih^T + b_ih, gates r|z|n, direction 0 = forward in time,
+ *   gi         [B][T][2][3][H] NATURAL layout -- the input GEMM's output as it is (no permute: the loads are 4 bytes
+ *                    per lane either way): x W_ih^T + b_ih, gates r|z|n, direction 0 = forward in time,
  *                    1 = reverse (fp32, or bf16 when is_bf16).  The recurrent biases of the r and z gates
  *                    (b_hh[0:2H]) must ALREADY be added in (they commute with the sigmoid argument).
  *   w_hh       [2][3H][H] bf16;   b_hn [2][H] fp32 (= b_hh[2H:3H] per direction);   h0 = 0
- *   y          [tiles*S][T][2H] natural layout (h_t; forward direction in [..., :H]), dtype of gi
+ *   y          [tiles*S][T][2H] natural layout (h_t; forward direction in [..., :H]), dtype of gi; rows >= B are
+ *                    scratch of the last tile's padding sequences (which re-read sequence B-1's gi)
  *   saved_tile       r, z, n, (W_hn h + b_hn) per step for the backward pass, or NULL: 2 pair-slots (r|z, n|gh_n),
  *                    i.e. [tile][t][dir][w(8)][2][lane(64)][2][U]; fp32 when gi is fp32, IEEE fp16 when is_bf16
  *                    (O(1) values: 8x finer than bf16 at half of fp32's bytes -- the recurrence is bound by one
  *                    CU's load/store path).  Opaque to the caller: tiles*T*2*8*2*64*2*U elements.
  * MFMA bf16 operands, fp32 accumulation, fp32 gates and state. */
 int64_t seld_gru_tile_rows(void);
-int seld_gru_forward(const void* gi_tile, int is_bf16, const void* w_hh_bf16, const float* b_hn, int64_t tiles,
+int seld_gru_forward(const void* gi, int is_bf16, const void* w_hh_bf16, const float* b_hn, int64_t B,
                      int64_t T, int64_t H, void* y, void* saved_tile, void* stream);
 
 /* Backward of the recurrence.  dy_tile NS=1 (dtype of y), y = the forward output (all tiles*S rows),

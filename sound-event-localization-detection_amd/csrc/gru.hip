@@ -188,12 +188,12 @@ __device__ __forceinline__ int lane_unit0(int wave, int lane) {
 }
 
 struct GruFwdArgs {
-  const void* gi;        // tile layout, NS = 3 (r | z | n), dtype T; r/z already include b_hh
+  const void* gi;        // [B][T][2][3][H] natural layout (the input GEMM's output), dtype T; r/z already include b_hh
   const __hip_bfloat16* w_hh;   // [2][3H][H]
   const float* b_hn;     // [2][H]    recurrent bias of the n gate
   void* y;               // [tiles*kSeqs][T][2H]  natural layout (what the next layer's GEMM reads), dtype T
   void* saved;           // tile layout, NS = 2 pairs (r|z, n|gh_n), Saved encoding (nullptr: inference)
-  long tiles, T;
+  long tiles, T, B;      // B sequences; the lanes of the last tile's padding sequences re-read sequence B-1
 };
 
 // The MFMA computes gh^T = W_hh h^T: M = gate rows (units), N = sequence columns; D[m = 4q+i][n = c].  The step
@@ -226,11 +226,13 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
   }
 
   auto time_of = [&](long step) { return dir == 0 ? step : a.T - 1 - step; };
+  const long b_read = b < a.B ? b : a.B - 1;
   auto load_gi = [&](long step, Group<D> (&g)[3]) {
-    // one base pointer per step + compile-time offsets (gate*64 groups): a single address register
-    const Group<D>* p = gi + tile_group(tile, a.T, time_of(step), dir, wave, 3, 0, lane);
+    // straight from the input GEMM's output (no layout permute): per wavefront load, kSeqs runs of 32 units (64 B in
+    // bf16), one per sequence; one base pointer per step + compile-time offsets (gate * H): a single address register
+    const Group<D>* p = gi + (((b_read * a.T + time_of(step)) * 2 + dir) * 3 * kH + unit0) / kU;
 #pragma unroll
-    for (int gate = 0; gate < 3; ++gate) g[gate] = p[gate * 64];
+    for (int gate = 0; gate < 3; ++gate) g[gate] = p[gate * (kH / kU)];
   };
 
   // `g` holds this step's operands on entry; they are unpacked at once and the same registers then receive the
@@ -692,15 +694,16 @@ int seld_gru_previous_state(const void* y, int elem_bytes, int64_t B, int64_t T,
 
 int64_t seld_gru_tile_rows(void) { return seld::kSeqs; }
 
-int seld_gru_forward(const void* gi_tile, int is_bf16, const void* w_hh_bf16, const float* b_hn, int64_t tiles,
+int seld_gru_forward(const void* gi, int is_bf16, const void* w_hh_bf16, const float* b_hn, int64_t B,
                      int64_t T, int64_t H, void* y, void* saved_tile, void* stream_) {
   using namespace seld;
   DeviceState* st = current_state();
   if (!st) return kErrNotInitialised;
   if (H != kH) return fail(kErrUnsupported, "seld_gru_forward: built for hidden size 256 (config.py:45)");
-  if (tiles <= 0 || T <= 0) return fail(kErrInvalidArgument, "seld_gru_forward: tiles and T must be positive");
-  if (!gi_tile || !w_hh_bf16 || !b_hn || !y) return fail(kErrInvalidArgument, "seld_gru_forward: null pointer");
-  GruFwdArgs a{gi_tile, static_cast<const __hip_bfloat16*>(w_hh_bf16), b_hn, y, saved_tile, tiles, T};
+  if (B <= 0 || T <= 0) return fail(kErrInvalidArgument, "seld_gru_forward: B and T must be positive");
+  if (!gi || !w_hh_bf16 || !b_hn || !y) return fail(kErrInvalidArgument, "seld_gru_forward: null pointer");
+  const long tiles = (B + kSeqs - 1) / kSeqs;
+  GruFwdArgs a{gi, static_cast<const __hip_bfloat16*>(w_hh_bf16), b_hn, y, saved_tile, tiles, T, B};
   const dim3 grid(static_cast<unsigned>(tiles), 2);
   const size_t lds = kWnBytes + 2 * kSeqs * kHPitch * sizeof(__hip_bfloat16);
   hipStream_t stream = static_cast<hipStream_t>(stream_);

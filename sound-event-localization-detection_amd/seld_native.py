@@ -648,8 +648,8 @@ def gru_forward(gi: torch.Tensor, w_hh: torch.Tensor, b_hn: torch.Tensor, need_s
     if two != 2 or h != GRU_H or gi.dtype not in (torch.float32, torch.bfloat16):
         raise ValueError("gru_forward: gi must be [B, T, 2, 768] float32 or bfloat16")
     index = ensure_init(gi.device)
-    gi_tile = to_tile_device(gi.reshape(b, t, 2, 3, h), 3)
-    tiles = gi_tile.shape[0]
+    gi = gi.contiguous()                    # read by the kernel as it is: the input GEMM's own output
+    tiles = (b + GRU_TILE - 1) // GRU_TILE
     w = w_hh.to(torch.bfloat16).contiguous()
     bias = b_hn.to(torch.float32).contiguous()
     if tuple(bias.shape) != (2, h):
@@ -659,7 +659,7 @@ def gru_forward(gi: torch.Tensor, w_hh: torch.Tensor, b_hn: torch.Tensor, need_s
     saved = torch.empty((tiles, t, 2, 8, 2, 64, 2, 8 * GRU_TILE // 16), dtype=saved_dtype, device=gi.device) \
         if need_saved else None
     with _device_guard(index):
-        check(load_library().seld_gru_forward(_p(gi_tile), int(gi.dtype == torch.bfloat16), _p(w), _p(bias), tiles, t,
+        check(load_library().seld_gru_forward(_p(gi), int(gi.dtype == torch.bfloat16), _p(w), _p(bias), b, t,
                                               h, _p(y), _p(saved), _stream_ptr(gi.device)), "seld_gru_forward")
     return y[:b], saved
 

@@ -39,16 +39,15 @@ t_b = timeit(lambda: seld_native.gru_backward(dy, saved, y, w))
 # kernel-only timings: pre-tiled operands straight through the C ABI
 lib = seld_native.load_library()
 P = seld_native._p
-gi_tile = seld_native.to_tile_device(gi.reshape(B, T, 2, 3, H), 3)
-tiles = gi_tile.shape[0]
+tiles = (B + seld_native.GRU_TILE - 1) // seld_native.GRU_TILE
 wb = w.to(torch.bfloat16).contiguous()
 wt = w.to(torch.bfloat16).transpose(1, 2).contiguous()
 yk = torch.empty((tiles * seld_native.GRU_TILE, T, 2 * H), dtype=torch.bfloat16, device=dev)
 dy_tile = seld_native.to_tile_device(dy.reshape(B, T, 2, 1, H), 1)
 dg_tile = torch.empty((tiles, T, 2, 8, 2, 64, 2, seld_native.GRU_TILE // 2), dtype=torch.bfloat16, device=dev)
 st = seld_native._stream_ptr(dev)
-k_f = timeit(lambda: lib.seld_gru_forward(P(gi_tile), 1, P(wb), P(bn), tiles, T, H, P(yk), P(saved), st))
-k_i = timeit(lambda: lib.seld_gru_forward(P(gi_tile), 1, P(wb), P(bn), tiles, T, H, P(yk), None, st))
+k_f = timeit(lambda: lib.seld_gru_forward(P(gi), 1, P(wb), P(bn), B, T, H, P(yk), P(saved), st))
+k_i = timeit(lambda: lib.seld_gru_forward(P(gi), 1, P(wb), P(bn), B, T, H, P(yk), None, st))
 dbias = torch.empty((tiles, 2, 4, H), device=dev)
 k_b = timeit(lambda: lib.seld_gru_backward(P(dy_tile), P(saved), P(yk), 1, P(wt), tiles, T, H, P(dg_tile), P(dbias), st))
 print(f"[{seld_native.GRU_TILE} sequences per tile] kernels only: forward {k_f * 1e3:.0f} us ({k_f * 1e3 / T:.2f} us/step)  forward(no save) {k_i * 1e3:.0f} us "
