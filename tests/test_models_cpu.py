@@ -102,3 +102,19 @@ def test_loss_accepts_compact_mask_labels():
     logits = torch.randn(2, 3, 648, 14, generator=g)
     crit = loss.SMRSELDLoss("mse", grid_size=(18, 36))
     assert crit(logits, mask)[0].item() == crit(logits, dense)[0].item()
+
+
+def test_run_head_on_cpu_is_the_stock_sequential():
+    """seld_layernorm.run_head only rewrites the head on a ROCm device; on the CPU (BASELINE configs[0]) it must be
+    the Sequential itself, also for a head that does not have the five-module shape."""
+    import torch
+    import torch.nn as nn
+    import seld_layernorm
+    from seld_linear import SeldLinear
+    torch.manual_seed(0)
+    head = nn.Sequential(SeldLinear(16, 512), nn.LayerNorm(512), nn.ReLU(), nn.Dropout(0.3), SeldLinear(512, 10)).eval()
+    x = torch.randn(3, 7, 16)
+    assert torch.equal(seld_layernorm.run_head(head, x), head(x))
+    assert not seld_layernorm.applicable(head[1], head[0](x))
+    odd = nn.Sequential(nn.Linear(16, 4), nn.Tanh())
+    assert torch.equal(seld_layernorm.run_head(odd, x), odd(x))
