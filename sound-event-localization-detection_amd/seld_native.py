@@ -101,7 +101,10 @@ def load_library():
                 raise SeldNativeError(
                     f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     f"or `make -C {_HERE / 'csrc'}`.  There is no CPU fallback.")
-            _lib = _declare(ctypes.CDLL(str(LIB_PATH)))
+            lib = _declare(ctypes.CDLL(str(LIB_PATH)))
+            global GRU_TILE
+            GRU_TILE = int(lib.seld_gru_tile_rows())       # geometry of THIS build, before anything sizes a buffer
+            _lib = lib
         return _lib
 
 
@@ -566,14 +569,14 @@ def dwconv1d_wgrad(x: torch.Tensor, dy: torch.Tensor, k: int):
 # --------------------------------------------------------------------------- GRU recurrence
 
 GRU_H = 256
-GRU_TILE = 8          # sequences per workgroup; refreshed from seld_gru_tile_rows() when the library is loaded
+GRU_TILE = 4          # sequences per workgroup; set from seld_gru_tile_rows() by load_library()
 
 
 def _tile_geometry():
-    """(sequences per tile, lanes sharing a sequence, units per lane) of the loaded library (8, 2, 4) or (4, 4, 2)."""
-    global GRU_TILE
+    """(sequences per tile, lanes sharing a sequence, units per lane) of the loaded library (8, 2, 4) or (4, 4, 2).
+    Without a built library (CPU-only checks of the torch layout definitions) the default build's geometry."""
     if LIB_PATH.exists():
-        GRU_TILE = int(load_library().seld_gru_tile_rows())
+        load_library()
     parts = 16 // GRU_TILE
     return GRU_TILE, parts, 8 // parts
 

@@ -94,7 +94,10 @@ def test_eval_mode_uses_running_statistics(gpu_device):
     assert torch.equal(rm, bn.running_mean) and torch.equal(rv, bn.running_var)
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 11, 8), (32, 64, 250, 64), (32, 512, 250, 8)])
+# (8, 16, 250, 64) ... (8, 32, 250, 8): the four blocks of the CRNN_CNN_CHANNELS = [16, 16, 32, 32], batch-8 model of
+# tests/test_master_weights_gpu.py -- two and four threads per row, the narrowest geometry the kernels accept beside C = 8
+@pytest.mark.parametrize("shape", [(2, 64, 11, 8), (32, 64, 250, 64), (32, 512, 250, 8), (8, 16, 250, 64),
+                                   (8, 16, 250, 32), (8, 32, 250, 16), (8, 32, 250, 8)])
 def test_bf16_block_matches_fp32_reference(gpu_device, shape):
     """The ConvBlock module path under bf16: fused tail vs the stock modules in fp32 on the same bf16 conv output."""
     import seld_native

@@ -125,3 +125,121 @@ def test_previous_state_is_y_shifted_in_each_directions_time_order(dtype, shape)
     want[:, 1:, 0] = yv[:, :-1, 0]
     want[:, :-1, 1] = yv[:, 1:, 1]
     assert torch.equal(got.view(b, t, 2, 256), want)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The bf16 build: gru_forward_kernel<bf16> WITH fp16 saves and gru_backward_kernel<bf16> -- the two kernels a training
+# iteration actually runs (the tests above feed fp32 and therefore exercise the <float> instantiations only).
+# Oracle: oracle/gru.py::recurrence_forward / recurrence_backward with the kernels' rounding points (bf16 MFMA operands,
+# bf16 y / dg stores, fp16 saves), pinned on the CPU to torch.nn.GRU and to autograd (tests/test_oracle_cpu.py).
+
+BF16_ULP = 2.0 ** -8            # spacing of bf16 in [0.5, 1): |y| <= 1
+
+
+def _recurrence_case(batch, steps, seed):
+    g = torch.Generator().manual_seed(seed)
+    k = 1.0 / H ** 0.5
+    gi = (torch.randn(batch, steps, 2, 3 * H, generator=g) * 1.2).to(torch.bfloat16)
+    w_hh = (torch.rand(2, 3 * H, H, generator=g) * 2 - 1) * 2 * k
+    b_hn = (torch.rand(2, H, generator=g) * 2 - 1) * k
+    dy = (torch.randn(batch, steps, 2 * H, generator=g) * 0.5).to(torch.bfloat16)
+    return gi, w_hh, b_hn, dy
+
+
+def _decode_saved(saved, batch):
+    """The forward kernel's saved-gate tensor (pair-slot tile layout, fp16) -> (r, z, n, g), each [B, T, 2, H] fp32."""
+    import seld_native
+    seqs = seld_native.GRU_TILE
+    tiles, t = saved.shape[0], saved.shape[1]
+    v = saved.view(tiles, t, 2, 8, 2, 4, 16 // seqs, seqs, 2, seqs // 2)
+    rzn, g = seld_native.from_pair_tile(v, batch)
+    return rzn[:, :, :, 0].float().cpu(), rzn[:, :, :, 1].float().cpu(), rzn[:, :, :, 2].float().cpu(), g.float().cpu()
+
+
+RECURRENCE_SHAPES = [(32, 250), (8, 250), (6, 40), (6, 41), (37, 20), (9, 5), (1, 1), (3, 2)]
+
+
+@pytest.mark.parametrize("batch,steps", RECURRENCE_SHAPES)
+def test_bf16_forward_with_saves_matches_rounding_aware_oracle(gpu_device, batch, steps):
+    import seld_native
+    gi, w_hh, b_hn, _ = _recurrence_case(batch, steps, 11)
+    y, saved = seld_native.gru_forward(gi.to(gpu_device), w_hh.to(gpu_device), b_hn.to(gpu_device), True)
+    assert y.dtype == torch.bfloat16 and saved.dtype == torch.float16          # the bf16 instantiation, with saves
+    y_ref, saved_ref = ogru.recurrence_forward(gi.float(), w_hh, b_hn, low=True)
+    err = (y.float().cpu() - y_ref).abs()
+    # a result within rounding noise of a bf16 tie may round the other way and is then one ulp off; nothing more
+    assert err.max().item() <= BF16_ULP + 1e-3, err.max().item()
+    assert (err > 0).float().mean().item() <= 0.02 and err.mean().item() <= 2e-5
+    for got, want, name in zip(_decode_saved(saved, batch), saved_ref, "rzng"):
+        e = (got - want).abs()
+        assert e.max().item() <= 2.0 ** -10 * max(1.0, want.abs().max().item()) + 1e-3, name   # fp16 ulp + drift
+        assert e.mean().item() <= 2e-5, name
+    # the no-save variant (inference) must produce the same y bit for bit
+    y2, none = seld_native.gru_forward(gi.to(gpu_device), w_hh.to(gpu_device), b_hn.to(gpu_device), False)
+    assert none is None and torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("batch,steps", RECURRENCE_SHAPES)
+def test_bf16_backward_matches_rounding_aware_oracle_and_autograd(gpu_device, batch, steps):
+    import seld_native
+    gi, w_hh, b_hn, dy = _recurrence_case(batch, steps, 12)
+    y, saved = seld_native.gru_forward(gi.to(gpu_device), w_hh.to(gpu_device), b_hn.to(gpu_device), True)
+    dgi, dghn, dbias = seld_native.gru_backward(dy.to(gpu_device), saved, y, w_hh.to(gpu_device))
+    assert dgi.dtype == torch.bfloat16 and tuple(dgi.shape) == (batch, steps, 2, 3, H)
+    assert tuple(dghn.shape) == (batch, steps, 2, H) and tuple(dbias.shape) == (2, 4, H) and dbias.dtype == torch.float32
+
+    # (1) the backward kernel alone: same saved activations and y as it read, rounding points restated
+    ref_gi, ref_n, ref_b = ogru.recurrence_backward(dy.float(), _decode_saved(saved, batch), y.float().cpu(), w_hh, low=True)
+
+    def check(got, want, name, rel_l2, ulps):
+        got, want = got.float().cpu(), want.float()
+        scale = want.abs().max().item() + 1e-12
+        err = (got - want).abs()
+        assert (err <= ulps * 2.0 ** -8 * want.abs() + 2e-3 * scale).all(), f"{name}: max err {err.max().item():.3e} at scale {scale:.3e}"
+        l2 = (got - want).norm().item() / (want.norm().item() + 1e-12)
+        assert l2 <= rel_l2, f"{name}: relative L2 {l2:.3e}"
+    check(dgi, ref_gi, "dgi", 2e-3, 2)
+    check(dghn, ref_n, "dghn", 2e-3, 2)
+    check(dbias, ref_b, "dbias", 1e-3, 0)
+
+    # (2) against plain fp32 autograd through the unrounded recurrence: what bf16 / fp16 storage costs
+    _, auto_gi, _, auto_bn = ogru.recurrence_autograd(gi.float(), w_hh.bfloat16().float(), b_hn, dy.float())
+    auto_gi = auto_gi.view(batch, steps, 2, 3, H)
+    l2 = (dgi.float().cpu() - auto_gi).norm().item() / (auto_gi.norm().item() + 1e-12)
+    assert l2 <= 2e-2, f"dgi vs autograd: relative L2 {l2:.3e}"
+    assert (dbias[:, 3].cpu() - auto_bn).abs().max().item() <= 2e-2 * (auto_bn.abs().max().item() + 1e-6) + 2e-3
+    want_b = auto_gi.sum(dim=(0, 1))                                                   # [2, 3, H]
+    assert (dbias[:, :3].cpu() - want_b).abs().max().item() <= 2e-2 * (want_b.abs().max().item() + 1e-6) + 2e-3
+
+
+@pytest.mark.parametrize("batch,steps", [(6, 40), (6, 41), (9, 5), (32, 250)])
+def test_bf16_module_gradients_match_oracle_autograd(gpu_device, batch, steps):
+    """SeldGRU under bf16 autocast (bf16 instantiations of both kernels + the host GEMMs of seld_gru._BiGRULayer):
+    dx, dW_ih, dW_hh and all four bias gradients against the oracle's autograd, ragged batches included."""
+    from seld_rnn import SeldGRU
+    torch.manual_seed(6)
+    m = SeldGRU(input_size=96, hidden_size=H, num_layers=1, batch_first=True, bidirectional=True).to(gpu_device)
+    x = torch.randn(batch, steps, 96, device=gpu_device, requires_grad=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y, _ = m(x)
+    assert y.dtype == torch.bfloat16
+    go = torch.randn(batch, steps, 2 * H, device=gpu_device)
+    (y.float() * go).sum().backward()
+
+    cpu = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.named_parameters()}
+    xc = x.detach().cpu().clone().requires_grad_(True)
+    ref = ogru.bigru_layer(xc, [cpu["weight_ih_l0"], cpu["weight_ih_l0_reverse"]],
+                           [cpu["bias_ih_l0"], cpu["bias_ih_l0_reverse"]],
+                           [cpu["weight_hh_l0"], cpu["weight_hh_l0_reverse"]],
+                           [cpu["bias_hh_l0"], cpu["bias_hh_l0_reverse"]], exact=False)
+    assert (y.float().cpu() - ref.detach()).abs().max().item() <= 2e-2          # bf16 input projection + bf16 y
+    (ref * go.cpu()).sum().backward()
+
+    def rel_l2(a, b):
+        return (a.float().cpu() - b).norm().item() / (b.norm().item() + 1e-12)
+    assert rel_l2(x.grad, xc.grad) <= 3e-2, ("dx", rel_l2(x.grad, xc.grad))
+    names = [n for n, _ in m.named_parameters()]
+    assert sorted(names) == sorted(["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse",
+                                    "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse"])
+    for name, p in m.named_parameters():
+        assert p.grad is not None and rel_l2(p.grad, cpu[name].grad) <= 3e-2, (name, rel_l2(p.grad, cpu[name].grad))

@@ -51,7 +51,8 @@ def test_rasteriser_edge_cases(gpu_device):
     rows = np.array([[9, 2, 0, 0, 0], [10, 3, 0, 0, 0], [400, 4, 0, 0, 0]])
     T = 48
     got = seld_native.rasterise_labels(torch.from_numpy(rows), T, device=gpu_device).cpu().numpy()
-    assert np.array_equal(got, olab.metadata_to_mask(rows, T * 480)) or True
+    assert olab.total_label_frames(T * 480) == T                  # the oracle takes SAMPLES: 48 frames of 480
+    assert np.array_equal(got, olab.metadata_to_mask(rows, T * 480))
     cell = 9 * 36 + 18
     assert (got[45:48, cell] == (1 << 2)).all() and got[:45].sum() == 0
     with pytest.raises(IndexError):
