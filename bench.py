@@ -29,15 +29,24 @@ The JSON line also carries
   cpu_baseline  : the oracle (torch CPU restatement of the reference path) timed on this host's
                   cores on a bounded sample -- a reported, non-target number.
 
+Launching N > 1 ranks.  Under torchrun (RANK / WORLD_SIZE set, the driver's form) this process IS one rank.  Started
+plainly as ``python bench.py --gpus N`` it has not touched the GPU yet (``torch.cuda.device_count()`` does not initialise
+it): it starts ``python -m torch.distributed.run --nproc-per-node N ... bench.py`` as a CHILD process, forwards the
+child's output and exits with its code -- one rank per GPU over RCCL.  It refuses (exit code 2, nothing launched) when
+fewer than N GPUs are visible, unless ``--rehearse-gloo`` (or SELD_DIST_BACKEND=gloo) asks for the rehearsal mode in
+which the N ranks share the visible GPU(s) over gloo: that exercises DDP, the sharded device feed and the replica
+agreement check on a one-GPU box and is never a measurement (the line says ``"rehearsal": true``).
+
 Other workloads (parity / coverage cases of BASELINE.json, not the headline): --model conformer | resnet_conformer;
---features logmel_gcc --channels 8 (configs[3]'s per-GPU shard: 8-ch MIC array, 36 input channels);
-SELD_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the DDP path (never a measurement).
+--features logmel_gcc --channels 8 (configs[3]'s per-GPU shard: 8-ch MIC array, 36 input channels).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -63,6 +72,9 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0    # dense bf16
 BYTES_PER_CLIP = CHANNELS * CLIP_SAMPLES * 4 + CHANNELS * 64 * (1 + CLIP_SAMPLES // 480) * 4   # 26.11 MB
 # fwd+bwd GFLOP per 250-frame window, hook-counted on the reference modules
 GFLOP_PER_WINDOW = {"crnn": 39.4, "conformer": 37.9, "resnet_conformer": 165.5}
+# which BASELINE.json entry a --model run corresponds to (the headline metric is quoted on configs[1])
+BASELINE_CONFIG = {"crnn": "BASELINE configs[1]", "conformer": "BASELINE configs[2]",
+                   "resnet_conformer": "BASELINE configs[4]'s model, class-MSE loss, one GPU"}
 
 
 def parse_args():
@@ -77,7 +89,38 @@ def parse_args():
                     help="feature set (logmel = the reference; logmel_gcc with --channels 8 = BASELINE configs[3]'s "
                          "per-GPU shard: 8-ch MIC, 8 log-mel + 28 GCC-PHAT input channels)")
     ap.add_argument("--channels", type=int, default=4, help="audio channels of the synthetic clips")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="N ranks share the visible GPU(s) over gloo (DDP rehearsal on a one-GPU box; not a measurement)")
     return ap.parse_args()
+
+
+def launch_ranks(args) -> int:
+    """``python bench.py --gpus N`` without torchrun: become the launcher.  Nothing here touches the GPU (a process
+    that has initialised HIP must not be replaced or forked into ranks), the ranks are children of a child
+    ``torch.distributed.run`` and this process only relays their output and exit code."""
+    visible = torch.cuda.device_count()                 # does not initialise the GPU on this image
+    rehearsal = args.rehearse_gloo or os.environ.get("SELD_DIST_BACKEND", "nccl") == "gloo"
+    if visible < 1:
+        print("bench.py: no ROCm GPU visible (the HIP extension has no CPU fallback)", file=sys.stderr)
+        return 2
+    if visible < args.gpus and not rehearsal:
+        print(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, {visible} visible.  One rank per GPU over RCCL is the "
+              f"only measured mode; pass --rehearse-gloo to rehearse the {args.gpus}-rank path on {visible} GPU(s) "
+              f"(DDP over gloo, ranks share the device; never a measurement).", file=sys.stderr)
+        return 2
+    if rehearsal and args.gpus > 6:
+        print("bench.py: a rehearsal keeps at most 6 ranks on one GPU", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:                       # a free rendezvous port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+    env["SELD_DIST_BACKEND"] = "gloo" if rehearsal else "nccl"
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def synth_metadata(clip_idx: int, meta_frames: int = 600) -> np.ndarray:
@@ -110,7 +153,7 @@ def synth_clip_batch(seed: int, device, channels=CHANNELS):
 class HotPath:
     """Holds the device-resident inputs and runs one step."""
 
-    def __init__(self, args, device, rank, world):
+    def __init__(self, args, device, rank, world, backend="nccl"):
         import seld_native
         import trainer
         self.native, self.trainer, self.device = seld_native, trainer, device
@@ -120,7 +163,7 @@ class HotPath:
         cfg.AMP_DTYPE = "fp32" if args.fp32 else "bf16"
         # identical initial weights on every rank; the gloo rehearsal mode seeds the ranks DIFFERENTLY on purpose so
         # that it exercises what makes them agree (DDP's parameter broadcast + the master-weight broadcast)
-        torch.manual_seed(rank if os.environ.get("SELD_DIST_BACKEND", "nccl") != "nccl" else 0)
+        torch.manual_seed(rank if backend != "nccl" else 0)
         self.features, self.channels = args.features, args.channels
         extra = {"logmel": 0, "logmel_iv": 3, "logmel_gcc": args.channels * (args.channels - 1) // 2}[args.features]
         self.feature_channels = args.channels + extra
@@ -264,45 +307,55 @@ def kernel_rooflines(device):
 
 
 def cpu_baseline():
-    """Oracle path on the host cores, bounded sample (about 20-30 s): log-mel of 2 clips via the
-    torch.stft restatement, reference-equivalent CRNN fwd+bwd+Adam at batch 2 (3 iterations after
-    1 warm-up), and the reference's pure-Python label loops on a 2 s excerpt (reported in `sample`)."""
+    """The oracle path on this host's cores, on a bounded sample (SURVEY.md section 8d protocol): log-mel by the torch.stft
+    restatement, 3 warm-up + 10 timed 60 s clips; reference-equivalent fp32 CRNN forward + loss + backward + Adam at
+    batch 2, 1 warm-up + 5 timed iterations.  Threads: min(16, cores) -- the share of host cores one GPU of the box has;
+    a batch-2 model on all 128 hardware threads runs slower, not faster (oversubscription).  The reference's pure-Python
+    label loops are timed on a 2 s excerpt and reported in `sample`, not included."""
     from oracle import features as ofeat
     from oracle import labels as olab
     import model_crnn
     import loss as loss_mod
-    threads = torch.get_num_threads()
-    pcm = ofeat.synth_pcm(0, CHANNELS, CLIP_SAMPLES, "noise")
-    ofeat.logmel_torch(pcm[:, :240000])                              # warm-up
-    t0 = time.perf_counter()
-    n_feat = 2
-    for _ in range(n_feat):
-        ofeat.logmel_torch(pcm)
-    t_feat = (time.perf_counter() - t0) / n_feat
-    rows = olab.synth_metadata(0, meta_frames=20)
-    t0 = time.perf_counter()
-    olab.metadata_to_labels_loops(rows, 48000)
-    t_label_loops_60s = (time.perf_counter() - t0) * 30.0            # 2 s excerpt -> 60 s, linear in frames
-    torch.manual_seed(0)
-    model = model_crnn.SELD_CRNN().train()
-    crit = loss_mod.SMRSELDLoss(loss_type="mse", w_class=1.0, grid_size=(18, 36))
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
-    x = torch.randn(2, WINDOW, CHANNELS, 64) * 20 - 30
-    y = torch.zeros(2, WINDOW, 648, 14)
-    y[..., 13] = 1.0
-    times = []
-    for it in range(4):
+    before = torch.get_num_threads()
+    threads = max(1, min(16, os.cpu_count() or 1))
+    torch.set_num_threads(threads)
+    try:
+        pcm = ofeat.synth_pcm(0, CHANNELS, CLIP_SAMPLES, "noise")
+        for _ in range(3):
+            ofeat.logmel_torch(pcm)                                     # warm-up
+        feat = []
+        for _ in range(10):
+            t0 = time.perf_counter()
+            ofeat.logmel_torch(pcm)
+            feat.append(time.perf_counter() - t0)
+        t_feat = float(np.median(feat))
+        rows = olab.synth_metadata(0, meta_frames=20)
         t0 = time.perf_counter()
-        opt.zero_grad()
-        out, _ = crit.loss_tensor(model(x), y)
-        out.backward()
-        opt.step()
-        times.append(time.perf_counter() - t0)
-    t_window = float(np.mean(times[1:])) / 2.0
+        olab.metadata_to_labels_loops(rows, 48000)
+        t_label_loops_60s = (time.perf_counter() - t0) * 30.0          # 2 s excerpt -> 60 s, linear in frames
+        torch.manual_seed(0)
+        model = model_crnn.SELD_CRNN().train()
+        crit = loss_mod.SMRSELDLoss(loss_type="mse", w_class=1.0, grid_size=(18, 36))
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+        x = torch.randn(2, WINDOW, CHANNELS, 64) * 20 - 30
+        y = torch.zeros(2, WINDOW, 648, 14)
+        y[..., 13] = 1.0
+        times = []
+        for it in range(6):
+            t0 = time.perf_counter()
+            opt.zero_grad()
+            out, _ = crit.loss_tensor(model(x), y)
+            out.backward()
+            opt.step()
+            times.append(time.perf_counter() - t0)
+        t_window = float(np.median(times[1:])) / 2.0
+    finally:
+        torch.set_num_threads(before)
     clip_seconds = t_feat + 60.0 * t_window
     return {
         "value": 1.0 / clip_seconds, "unit": "clips/s", "cores": threads, "kind": "port",
-        "sample": (f"oracle on host: log-mel 2x60s clips {t_feat * 1e3:.0f} ms/clip; CRNN fwd+bwd+Adam fp32 bs=2, 3 iters "
+        "sample": (f"oracle on {threads} of {os.cpu_count()} host threads: log-mel 3 warm-up + 10 timed 60 s clips, median "
+                   f"{t_feat * 1e3:.0f} ms/clip; CRNN fwd+bwd+Adam fp32 bs=2, 1 warm-up + 5 timed iterations, median "
                    f"{t_window * 1e3:.0f} ms/window x 60 windows/clip; reference-style Python label loops would add "
                    f"{t_label_loops_60s:.1f} s/clip (not included)"),
         "features_clips_per_s": 1.0 / t_feat, "model_windows_per_s": 1.0 / t_window,
@@ -314,13 +367,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "RANK" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))          # BEFORE anything initialises the GPU in this process
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP extension has no CPU fallback)")
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # one rank per GPU; SELD_DIST_BACKEND=gloo is a rehearsal mode that lets several ranks share one GPU (RCCL refuses
-    # that) to exercise DDP with the HIP autograd functions on a single-GPU box -- never a measurement
-    backend = os.environ.get("SELD_DIST_BACKEND", "nccl")
+    # one rank per GPU over RCCL; gloo = the rehearsal mode in which ranks may share a GPU (RCCL refuses that)
+    backend = "gloo" if args.rehearse_gloo else os.environ.get("SELD_DIST_BACKEND", "nccl")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"{world} ranks over RCCL need {world} GPUs ({torch.cuda.device_count()} visible); "
+                         f"--rehearse-gloo rehearses on fewer")
     index = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(index)
     device = torch.device("cuda", index)
@@ -332,7 +391,7 @@ def main():
             dist.init_process_group(backend=backend)
     torch.backends.cudnn.benchmark = True
 
-    hot = HotPath(args, device, rank, world)
+    hot = HotPath(args, device, rank, world, backend)
     for _ in range(args.warmup):
         hot.step(timed=False)
     torch.cuda.synchronize()
@@ -347,15 +406,20 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(t.item()) for t in every]
+        elapsed = max(per_rank)                               # the job is as slow as its slowest rank
 
     in_sync = None
     if world > 1:       # every replica must hold the same weights after the timed steps (sum of all parameters)
         with torch.no_grad():
             total = sum(p.double().sum() for p in hot.model.parameters()).reshape(1)
+        if backend != "nccl":
+            total = total.cpu()
         hi, lo = total.clone(), total.clone()
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
@@ -377,7 +441,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32" if args.fp32 else "bf16", "data": "synthetic",
-            "config": {"workload": (f"{args.model} FOA 4-ch 60s clips, bs={BATCH} windows (BASELINE configs[1])"
+            "config": {"workload": (f"{args.model} FOA 4-ch 60s clips, bs={BATCH} windows ({BASELINE_CONFIG[args.model]})"
                                     if args.features == "logmel" and args.channels == 4 else
                                     f"{args.model} {args.channels}-ch 60s clips, features {args.features} "
                                     f"({hot.feature_channels} input channels), bs={BATCH} windows per GPU"),
@@ -399,8 +463,12 @@ def main():
                                "bound": "mfma", "achieved": model_tflops, "peak": MFMA_BF16_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": model_tflops / MFMA_BF16_PEAK_TFLOPS, "avg_ms": model_ms},
         }
-        if in_sync is not None:
+        if world > 1:
+            line["config"]["backend"] = "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend
             line["config"]["replicas_in_sync"] = in_sync
+            line["config"]["per_rank_clips_per_s"] = [CLIPS_PER_STEP * args.steps / t for t in per_rank]
+            if backend != "nccl":
+                line["rehearsal"] = True          # ranks share a GPU over gloo: a functional check, not a measurement
         if hasattr(hot.optimizer, "fused_casts"):
             line["config"]["master_weights"] = {"one_launch_gradient_casts": hot.optimizer.fused_casts,
                                                 "per_tensor_fallbacks": hot.optimizer.fallback_casts}

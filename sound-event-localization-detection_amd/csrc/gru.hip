@@ -707,13 +707,12 @@ int seld_gru_forward(const void* gi, int is_bf16, const void* w_hh_bf16, const f
   const dim3 grid(static_cast<unsigned>(tiles), 2);
   const size_t lds = kWnBytes + 2 * kSeqs * kHPitch * sizeof(__hip_bfloat16);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  static bool attr_done = false;          // not a stream operation: do it once so launches stay graph-capturable
-  if (!attr_done) {
+  if (need_lds(st, kAttrGruForward)) {     // once per device (seld_common.h)
     SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_forward_kernel<__hip_bfloat16>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_forward_kernel<float>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    attr_done = true;
+    lds_attr_set(st, kAttrGruForward);
   }
   if (is_bf16) hipLaunchKernelGGL(gru_forward_kernel<__hip_bfloat16>, grid, dim3(kGruThreads), lds, stream, a);
   else hipLaunchKernelGGL(gru_forward_kernel<float>, grid, dim3(kGruThreads), lds, stream, a);
@@ -735,13 +734,12 @@ int seld_gru_backward(const void* dy_tile, const void* saved_tile, const void* y
   const dim3 grid(static_cast<unsigned>(tiles), 2);
   const size_t lds = kWnBytes + 2 * kSeqs * kDghPitch * sizeof(__hip_bfloat16);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  static bool attr_done = false;
-  if (!attr_done) {
+  if (need_lds(st, kAttrGruBackward)) {
     SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_backward_kernel<__hip_bfloat16>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_backward_kernel<float>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    attr_done = true;
+    lds_attr_set(st, kAttrGruBackward);
   }
   if (is_bf16) hipLaunchKernelGGL(gru_backward_kernel<__hip_bfloat16>, grid, dim3(kGruThreads), lds, stream, a);
   else hipLaunchKernelGGL(gru_backward_kernel<float>, grid, dim3(kGruThreads), lds, stream, a);

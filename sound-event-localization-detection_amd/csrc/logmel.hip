@@ -228,12 +228,11 @@ static int launch_stft(const T* pcm, int64_t N, int64_t C, int64_t L, float* out
   if (waves > max_waves) waves = max_waves;
   a.chunk = (total + waves - 1) / waves;
   const long used = (total + a.chunk - 1) / a.chunk;
-  static bool attr_done[2] = {false, false};
-  const int which = sizeof(T) == 4 ? 0 : 1;
-  if (!attr_done[which]) {
+  const unsigned bit = sizeof(T) == 4 ? kAttrStftF32 : kAttrStftI16;
+  if (need_lds(st, bit)) {                 // once per device (seld_common.h)
     SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(stft_kernel<T>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, kEdgeLdsBytes));
-    attr_done[which] = true;
+    lds_attr_set(st, bit);
   }
   hipLaunchKernelGGL(stft_kernel<T>, dim3(static_cast<unsigned>((used + kEdgeWaves - 1) / kEdgeWaves)),
                      dim3(kEdgeWaves * 64), kEdgeLdsBytes, stream, a);
@@ -285,14 +284,13 @@ static int launch_logmel(const T* pcm, int64_t N, int64_t C, int64_t L, float* o
   a.tab = st->tables();
   a.chunk = 1;
 
-  static bool attr_done[2] = {false, false};
-  const int which = sizeof(T) == 4 ? 0 : 1;
-  if (!attr_done[which]) {
+  const unsigned bit = sizeof(T) == 4 ? kAttrLogmelF32 : kAttrLogmelI16;
+  if (need_lds(st, bit)) {                 // once per device (seld_common.h)
     SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_main_kernel<T>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, kMainLdsBytes));
     SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_edge_kernel<T>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, kEdgeLdsBytes));
-    attr_done[which] = true;
+    lds_attr_set(st, bit);
   }
   const long n_edge = a.rows * a.edge_per_row;
   const long total = a.rows * a.interior;

@@ -42,8 +42,25 @@ struct DeviceState {
   // side stream + fork/join events: the tiny edge kernel of the log-mel path overlaps the main kernel
   hipStream_t side_stream = nullptr;
   hipEvent_t fork_event = nullptr, join_event = nullptr;
+  // kernels that need more dynamic LDS than the default limit: hipFuncSetAttribute is per DEVICE (and is not a stream
+  // operation: done once so that launches stay graph-capturable); one bit per kernel family, see need_lds()
+  unsigned lds_attr_done = 0;
   LogmelTables tables() const { return LogmelTables{window, twiddle, mel_b0, mel_wd, mel_wu}; }
 };
+
+enum LdsAttrBit : unsigned {
+  kAttrGruForward = 1u << 0,
+  kAttrGruBackward = 1u << 1,
+  kAttrStftF32 = 1u << 2,
+  kAttrStftI16 = 1u << 3,
+  kAttrLogmelF32 = 1u << 4,
+  kAttrLogmelI16 = 1u << 5,
+  kAttrSpatial = 1u << 6,
+};
+
+// true when `bit` still has to be set up on this device (the caller then sets its attributes and calls lds_attr_set)
+inline bool need_lds(const DeviceState* st, unsigned bit) { return (st->lds_attr_done & bit) == 0; }
+inline void lds_attr_set(DeviceState* st, unsigned bit) { st->lds_attr_done |= bit; }
 
 // Returns the state of the CURRENT hip device, or nullptr (and sets the error) if seld_init
 // has not been called for it.

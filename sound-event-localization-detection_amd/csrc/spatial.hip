@@ -265,11 +265,10 @@ int seld_gcc_phat(const float* spec_complex, int64_t N, int64_t C, int64_t F, fl
   const long cap = static_cast<long>(st->num_cus) * 4;
   if (blocks > cap) blocks = cap;
   const size_t lds = kGccLdsFloats * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  if (need_lds(st, kAttrSpatial)) {        // once per device (seld_common.h)
     SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gcc_phat_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    attr_done = true;
+    lds_attr_set(st, kAttrSpatial);
   }
   hipLaunchKernelGGL(gcc_phat_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kGccWaves * 64), lds,
                      static_cast<hipStream_t>(stream_), a);

@@ -125,10 +125,12 @@ def ensure_process_group(device):
     if world <= 1:
         return 0, 1
     if not dist.is_initialized():
-        backend = "nccl" if device.type == "cuda" else "gloo"
+        # SELD_DIST_BACKEND=gloo on a GPU: the rehearsal mode in which several ranks share one device (RCCL refuses
+        # that); gradients then travel through the host -- functional checks only
+        backend = os.environ.get("SELD_DIST_BACKEND") or ("nccl" if device.type == "cuda" else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if device.type == "cuda":
+        if device.type == "cuda" and backend == "nccl":
             torch.cuda.set_device(device)
             dist.init_process_group(backend=backend, device_id=device)
         else:
@@ -183,17 +185,45 @@ def shard_indices(order, rank, world, pad=True):
 # batch sources
 # ------------------------------------------------------------------------------------------------
 
-class LoaderFeed:
-    """The stock path: iterate the DataLoader the caller built (CPU tensors -> device)."""
+def epoch_order(n, shuffle, seed, epoch):
+    """The index order of one epoch: a seeded permutation (the same on every rank) or sequential."""
+    if shuffle:
+        g = torch.Generator().manual_seed(seed * 100003 + epoch)
+        return torch.randperm(n, generator=g).tolist()
+    return list(range(n))
 
-    def __init__(self, loader, device):
+
+def batched(order, batch_size, drop_last):
+    out = [order[lo:lo + batch_size] for lo in range(0, len(order), batch_size)]
+    return out[:-1] if drop_last and out and len(out[-1]) < batch_size else out
+
+
+class LoaderFeed:
+    """The stock path: iterate the DataLoader the caller built (CPU tensors -> device).  With more than one rank the
+    caller's loader would hand EVERY rank the full epoch (the reference is single-process: main.py:60-74 builds a plain
+    shuffling DataLoader), so the epoch's index order is sharded like DeviceFeed's and a loader with the caller's
+    batch size, workers, collate function and pinning is driven by an explicit batch sampler."""
+
+    def __init__(self, loader, device, rank=0, world=1, seed=0):
         self.loader, self.device = loader, device
+        self.rank, self.world, self.seed = rank, world, seed
+        self.shuffle = isinstance(getattr(loader, "sampler", None), RandomSampler)
+        if world > 1 and getattr(loader, "batch_size", None) is None:
+            raise ValueError("data-parallel training needs a DataLoader with a batch_size (got a batch_sampler-only loader)")
+
+    def _batches_of_rank(self, epoch):
+        order = shard_indices(epoch_order(len(self.loader.dataset), self.shuffle, self.seed, epoch), self.rank, self.world)
+        return batched(order, self.loader.batch_size, bool(self.loader.drop_last))
 
     def __len__(self):
-        return len(self.loader)
+        return len(self.loader) if self.world <= 1 else len(self._batches_of_rank(0))
 
     def batches(self, epoch):
-        for spectrograms, labels in self.loader:
+        loader = self.loader
+        if self.world > 1:
+            loader = DataLoader(loader.dataset, batch_sampler=self._batches_of_rank(epoch), num_workers=loader.num_workers,
+                                collate_fn=loader.collate_fn, pin_memory=loader.pin_memory)
+        for spectrograms, labels in loader:
             yield (spectrograms.to(self.device, non_blocking=True), labels.to(self.device, non_blocking=True))
 
 
@@ -210,24 +240,14 @@ class DeviceFeed:
         self.device, self.rank, self.world, self.seed = device, rank, world, seed
 
     def _order(self, epoch):
-        n = len(self.dataset)
-        if self.shuffle:
-            g = torch.Generator().manual_seed(self.seed * 100003 + epoch)
-            order = torch.randperm(n, generator=g).tolist()
-        else:
-            order = list(range(n))
-        return shard_indices(order, self.rank, self.world)
+        return shard_indices(epoch_order(len(self.dataset), self.shuffle, self.seed, epoch), self.rank, self.world)
 
     def __len__(self):
         n = len(shard_indices(range(len(self.dataset)), self.rank, self.world))
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
     def batches(self, epoch):
-        order = self._order(epoch)
-        for lo in range(0, len(order), self.batch_size):
-            idx = order[lo:lo + self.batch_size]
-            if self.drop_last and len(idx) < self.batch_size:
-                break
+        for idx in batched(self._order(epoch), self.batch_size, self.drop_last):
             yield self.dataset.device_batch(idx)
 
 
@@ -235,14 +255,12 @@ def make_feed(loader, device, rank, world):
     ds = loader.dataset
     use_device = (getattr(config, "DEVICE_FEED", True) and device.type == "cuda" and isinstance(ds, SELDDataset)
                   and getattr(ds, "spec_tm", None) is not None and loader.batch_size is not None)
+    seed = config.SEED if getattr(config, "SEED", None) is not None else random.randrange(1 << 30)
+    if world > 1:                          # every rank must draw the same permutation
+        seed = int(all_reduce_sums([float(seed) if rank == 0 else 0.0], device)[0])
     if use_device:
-        seed = config.SEED if getattr(config, "SEED", None) is not None else random.randrange(1 << 30)
-        if world > 1:                      # every rank must draw the same permutation
-            seed = int(all_reduce_sums([float(seed) if rank == 0 else 0.0], device)[0])
         return DeviceFeed(loader, device, rank, world, seed)
-    if world > 1:
-        logger.warning("stock DataLoader under torchrun: every rank iterates the full loader (no sharding)")
-    return LoaderFeed(loader, device)
+    return LoaderFeed(loader, device, rank, world, seed)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -543,7 +561,9 @@ def train_model(train_loader, test_loader, num_epochs=None, batch_size=None, lea
         "best_train_loss": best_train_loss, "best_test_loss": best_test_loss,
         "best_epoch": best_epoch, "total_epochs": epoch,
         "config": {"num_epochs": num_epochs, "batch_size": batch_size, "learning_rate": learning_rate,
-                   "grid_size": grid},
+                   "grid_size": grid,
+                   # not upstream: how the epoch was sharded (one process: world 1, every batch on this rank)
+                   "world_size": world, "batches_per_rank": len(train_feed), "batch_source": type(train_feed).__name__},
     }
     if is_main:
         history_path = config.OUTPUT_PATH / f"training_history_{stamp}.pth"

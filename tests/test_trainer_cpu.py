@@ -92,8 +92,10 @@ def _ddp_worker(rank, world, tmp, port, queue):
     test_loader = DataLoader(TinySeld(4, 2), batch_size=2, shuffle=False)
     model, history = trainer.train_model(train_loader, test_loader, device=torch.device("cpu"))
     flat = torch.cat([p.detach().flatten() for p in model.parameters()])
+    feed = trainer.make_feed(train_loader, torch.device("cpu"), rank, world)
+    seen = sorted(i for batch in feed._batches_of_rank(1) for i in batch)
     queue.put((rank, flat.double().sum().item(), flat.abs().double().sum().item(), history["train_losses"],
-               history["test_losses"], history["best_epoch"]))
+               history["test_losses"], history["best_epoch"], history["config"], seen))
     import torch.distributed as dist
     dist.barrier()
     dist.destroy_process_group()
@@ -112,7 +114,12 @@ def test_data_parallel_two_ranks_gloo(tmp_path):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    (_, s0, a0, tr0, te0, be0), (_, s1, a1, tr1, te1, be1) = results
+    (_, s0, a0, tr0, te0, be0, cfg0, seen0), (_, s1, a1, tr1, te1, be1, cfg1, seen1) = results
     assert s0 == s1 and a0 == a1
     assert tr0 == tr1 and te0 == te1 and be0 == be1
+    # the epoch really is sharded inside train_model: 8 windows, batch 2 -> 4 batches in one process, 2 per rank here,
+    # and the two ranks' index sets are disjoint and cover the dataset
+    assert cfg0["world_size"] == 2 and cfg0["batches_per_rank"] == 2 and cfg0["batch_source"] == "LoaderFeed"
+    assert cfg1["batches_per_rank"] == 2
+    assert not set(seen0) & set(seen1) and sorted(seen0 + seen1) == list(range(8))
     assert (Path(tmp_path) / "checkpoints" / "best_model.pth").exists()
