@@ -15,7 +15,8 @@ PCM and metadata are already resident in HBM when the timed region starts:
   3. crop to 3000 aligned frames per clip, concatenate, cut 1920 windows of 250 frames / hop 50
      (dataset.py:243-317: 60 windows per clip, windows straddle clip boundaries as upstream)
   4. 60 optimiser iterations of 32 windows: window gather -> CRNN forward (bf16 autocast) ->
-     fused softmax-MSE loss -> backward (RCCL all-reduce overlapped when N > 1) -> Adam.
+     fused softmax-MSE loss -> backward -> (N > 1: all-reduce of the flat gradient buffers over RCCL) -> Adam;
+     after three eager iterations the iteration is a replayed HIP graph (seld_graph.py; trainer.train_model's own path).
 clips/s = N * 32 * K / (max-over-ranks wall time); weak scaling (every rank has its own 32 clips).
 
 The JSON line also carries
@@ -169,11 +170,15 @@ class HotPath:
         self.feature_channels = args.channels + extra
         model = trainer.prepare_model_for_device(trainer.build_model((18, 36), n_channels=self.feature_channels), device)
         trainer.enable_master_weights(model, device)
-        self.model = trainer.wrap_ddp(model, device, world)
+        # exactly what trainer.train_model sets up: captured iterations with their own flat gradient exchange
+        # (seld_graph.py), or -- SELD_GRAPH_STEP=0 / Config.GRAPH_STEP off -- the eager loop under DistributedDataParallel
+        graphed = trainer.graph_step_enabled(device, world)
+        self.model = trainer.broadcast_replica_state(model, world) if graphed else trainer.wrap_ddp(model, device, world)
         weights = torch.ones(14, device=device)
         weights[13] = 0.05
         self.criterion = trainer.SMRSELDLoss(loss_type="mse", w_class=1.0, grid_size=(18, 36), class_weights=weights)
-        self.optimizer = trainer.make_optimizer(self.model, cfg.LEARNING_RATE, device)
+        self.optimizer = trainer.make_optimizer(self.model, cfg.LEARNING_RATE, device, capturable=graphed)
+        self.stepper = trainer.make_stepper(self.model, self.criterion, self.optimizer, device, world)
         self.pcm, self.events = synth_clip_batch(rank, device, args.channels)
         total = CLIPS_PER_STEP * FRAMES_PER_CLIP
         self.starts = torch.arange(0, total, HOP, dtype=torch.int64, device=device)          # 480 windows
@@ -207,7 +212,7 @@ class HotPath:
             starts = self.starts[lo:lo + BATCH]
             spec = nat.gather_windows(spec_tm, starts, WINDOW)
             mask = nat.gather_windows(self.mask_tm, starts, WINDOW)
-            last, _ = self.trainer.train_step(self.model, self.criterion, self.optimizer, spec, mask, dev)
+            last, _ = self.stepper(spec, mask)
         if timed:
             m1.record()
             self.model_events.append((m0, m1))
@@ -469,6 +474,7 @@ def main():
             line["config"]["per_rank_clips_per_s"] = [CLIPS_PER_STEP * args.steps / t for t in per_rank]
             if backend != "nccl":
                 line["rehearsal"] = True          # ranks share a GPU over gloo: a functional check, not a measurement
+        line["config"]["captured_step"] = hot.stepper.stats() if hasattr(hot.stepper, "stats") else None
         if hasattr(hot.optimizer, "fused_casts"):
             line["config"]["master_weights"] = {"one_launch_gradient_casts": hot.optimizer.fused_casts,
                                                 "per_tensor_fallbacks": hot.optimizer.fallback_casts}

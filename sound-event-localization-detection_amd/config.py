@@ -103,6 +103,9 @@ class Config:
     MASTER_WEIGHTS = True       # bf16 runs: the conv / Linear / GRU weight matrices live in the model as bf16 working
                                 # copies of fp32 masters owned by the optimiser (same values autocast would cast to
                                 # every iteration, without ~40-340 cast kernels per iteration; bf16 gradient all-reduce)
+    GRAPH_STEP = True           # one optimiser iteration = one replayed HIP graph per input shape (seld_graph.py): the eager
+                                # loop spends ~3.5 ms of host time enqueueing ~300 launches per CRNN iteration; data
+                                # parallel: graph (forward + backward) -> flat all-reduce -> graph (Adam)
     DDP_BUCKET_MB = 8           # RCCL all-reduce bucket size: with bf16 working weights the CRNN's gradients are 22 MB, so
                                 # 8 MB gives three buckets -- the head's (ready first) reduces under the GRU / conv backward
     SYNC_BATCHNORM = False      # per-rank BN statistics by default

@@ -311,15 +311,20 @@ def expand_labels(mask: torch.Tensor, num_classes: int = NUM_CLASSES) -> torch.T
     return out
 
 
-def gather_windows(src: torch.Tensor, starts: torch.Tensor, window: int) -> torch.Tensor:
-    """dataset.py:267-317: src [T, ...] (time-major rows) -> [B, window, ...], zero padded past T."""
+def gather_windows(src: torch.Tensor, starts: torch.Tensor, window: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    """dataset.py:267-317: src [T, ...] (time-major rows) -> [B, window, ...], zero padded past T.  ``out``: write into
+    this contiguous tensor of that shape (the static input buffer of a captured training step)."""
     if not src.is_cuda:
         raise SeldNativeError("gather_windows: src must be a GPU tensor")
     src = src.contiguous()
     row_bytes = src[0].numel() * src.element_size() if src.shape[0] else 0
     index = ensure_init(src.device)
     starts = starts.to(device=src.device, dtype=torch.int64).contiguous()
-    out = torch.empty((starts.numel(), window) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    shape = (starts.numel(), window) + tuple(src.shape[1:])
+    if out is None:
+        out = torch.empty(shape, dtype=src.dtype, device=src.device)
+    elif tuple(out.shape) != shape or out.dtype != src.dtype or out.device != src.device or not out.is_contiguous():
+        raise ValueError(f"gather_windows: out must be a contiguous {src.dtype} tensor of shape {shape} on {src.device}")
     if row_bytes == 0:
         raise ValueError("gather_windows: empty source")
     with _device_guard(index):

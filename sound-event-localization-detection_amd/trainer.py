@@ -151,6 +151,11 @@ def wrap_ddp(model, device, world):
     # DDP has just broadcast rank 0's parameters -- the bf16 working copies included.  The fp32 masters behind them
     # are not module parameters: broadcast them too (the reference never seeds, so every rank initialised its own)
     # and re-derive the working copies, or the ranks would part ways at the first optimiser step.
+    _broadcast_masters(model)
+    return ddp
+
+
+def _broadcast_masters(model):
     state = getattr(model, "_seld_master_weights", None)
     if state is not None:
         with torch.no_grad():
@@ -158,7 +163,18 @@ def wrap_ddp(model, device, world):
                 dist.broadcast(master, src=0)
             for p, master in zip(state[0], state[1]):
                 p.data.copy_(master)
-    return ddp
+
+
+def broadcast_replica_state(model, world):
+    """What constructing DistributedDataParallel does to the replicas, for the captured-step path that drives the
+    gradient exchange itself (seld_graph.py): every rank takes rank 0's parameters, buffers and fp32 masters."""
+    if world <= 1:
+        return model
+    with torch.no_grad():
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src=0)
+    _broadcast_masters(model)
+    return model
 
 
 def all_reduce_sums(values, device):
@@ -380,16 +396,37 @@ class MasterWeightAdam(torch.optim.Adam):
                 p.grad.zero_()
 
 
-def make_optimizer(model, learning_rate, device):
+def graph_step_enabled(device, world=1):
+    """Captured training iterations (seld_graph.py): ROCm device, Config.GRAPH_STEP, and no SyncBatchNorm (its
+    collectives sit inside the forward pass, which the captured path never interrupts)."""
+    return (device.type == "cuda" and bool(getattr(config, "GRAPH_STEP", True))
+            and os.environ.get("SELD_GRAPH_STEP", "1") != "0"
+            and not (world > 1 and getattr(config, "SYNC_BATCHNORM", False)))
+
+
+def make_optimizer(model, learning_rate, device, capturable=False):
     kwargs = dict(lr=learning_rate, weight_decay=config.WEIGHT_DECAY)
     if device.type == "cuda":
         kwargs["fused"] = True            # one multi-tensor kernel instead of ~4 launches per parameter
+        if capturable:                    # step count and learning rate live on the device (graph replay)
+            kwargs["capturable"] = True
+            kwargs["lr"] = torch.tensor(float(learning_rate), dtype=torch.float32, device=device)
     state = getattr(unwrap(model), "_seld_master_weights", None)
     if state is not None:
         low_ids = {id(p) for p in state[0]}
         others = [p for p in model.parameters() if id(p) not in low_ids]
         return MasterWeightAdam(state[0], state[1], others, **kwargs)
     return torch.optim.Adam(model.parameters(), **kwargs)
+
+
+def make_stepper(model, criterion, optimizer, device, world=1):
+    """The per-iteration callable of the epoch loop: ``(spectrograms, labels) -> (total, term)``.  On a ROCm device a
+    ``seld_graph.GraphedTrainStep`` (captured iteration, flat-buffer gradient exchange); otherwise ``train_step``."""
+    if graph_step_enabled(device, world) and not isinstance(model, torch.nn.parallel.DistributedDataParallel):
+        import seld_graph
+        return seld_graph.GraphedTrainStep(model, criterion, optimizer, device, world,
+                                           autocast=lambda: autocast_context(device))
+    return lambda spectrograms, labels: train_step(model, criterion, optimizer, spectrograms, labels, device)
 
 
 def checkpoint_payload(epoch, model, optimizer, train_loss, test_loss):
@@ -431,13 +468,17 @@ def train_model(train_loader, test_loader, num_epochs=None, batch_size=None, lea
     model = prepare_model_for_device(build_model(grid, use_small_model, n_channels=n_channels), device)
     n_params = sum(p.numel() for p in model.parameters())
     enable_master_weights(model, device)
-    model = wrap_ddp(model, device, world)
+    graphed = graph_step_enabled(device, world)
+    # captured iterations exchange gradients themselves (one flat all-reduce between two graph replays); the eager
+    # path keeps DistributedDataParallel's bucketed, overlapped reducer
+    model = broadcast_replica_state(model, world) if graphed else wrap_ddp(model, device, world)
 
     class_weights = torch.ones(config.NUM_CLASSES, device=device)
     class_weights[config.NUM_CLASSES - 1] = 0.05            # trainer.py:99-100
     criterion = SMRSELDLoss(loss_type=config.LOSS_TYPE, w_class=config.W_CLASS, w_aiur=config.W_AIUR,
                             w_cl=config.W_CL, grid_size=grid, class_weights=class_weights)
-    optimizer = make_optimizer(model, learning_rate, device)
+    optimizer = make_optimizer(model, learning_rate, device, capturable=graphed)
+    stepper = make_stepper(model, criterion, optimizer, device, world)
     scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=config.LR_DECAY_FACTOR,
                                                            patience=config.LR_DECAY_PATIENCE)
     logger.info(f"Model parameters: {n_params:,}")
@@ -465,12 +506,12 @@ def train_model(train_loader, test_loader, num_epochs=None, batch_size=None, lea
         bar = tqdm(train_feed.batches(epoch), total=len(train_feed), desc=f"Epoch {epoch}/{num_epochs} [Train]",
                    leave=False, disable=not is_main)
         for spectrograms, labels in bar:
-            total, term = train_step(model, criterion, optimizer, spectrograms, labels, device)
+            total, term = stepper(spectrograms, labels)
             loss_sum += total.double()
             term_sum += term.double()
             steps += 1
             if is_main and steps % 25 == 0:
-                bar.set_postfix({"loss": f"{total.item():.4f}", "lr": f"{optimizer.param_groups[0]['lr']:.6f}"})
+                bar.set_postfix({"loss": f"{total.item():.4f}", "lr": f"{float(optimizer.param_groups[0]['lr']):.6f}"})
         tr_loss, tr_term, tr_steps = all_reduce_sums([loss_sum.item(), term_sum.item(), float(steps)], device)
         avg_train_loss, avg_train_term = tr_loss / max(tr_steps, 1.0), tr_term / max(tr_steps, 1.0)
 
@@ -492,9 +533,9 @@ def train_model(train_loader, test_loader, num_epochs=None, batch_size=None, lea
         train_losses.append(avg_train_loss)
         test_losses.append(avg_test_loss)
 
-        old_lr = optimizer.param_groups[0]["lr"]
+        old_lr = float(optimizer.param_groups[0]["lr"])
         scheduler.step(avg_test_loss)
-        new_lr = optimizer.param_groups[0]["lr"]
+        new_lr = float(optimizer.param_groups[0]["lr"])
         if new_lr != old_lr:
             logger.info(f"  Learning rate reduced: {old_lr:.6f} -> {new_lr:.6f}")
 
@@ -549,6 +590,9 @@ def train_model(train_loader, test_loader, num_epochs=None, batch_size=None, lea
         plot_loss_curves(train_losses, test_losses, save_path=config.OUTPUT_PATH / f"loss_curves_{stamp}.png")
     if world > 1:
         dist.barrier()
+    if hasattr(stepper, "close"):
+        logger.info(f"Captured training step: {stepper.stats()}")
+        stepper.close()
     disable_master_weights(model)                 # the returned model holds plain fp32 parameters again
     best_path = config.CHECKPOINT_PATH / "best_model.pth"
     if best_path.exists():

@@ -1,0 +1,85 @@
+"""The captured training iteration (seld_graph.GraphedTrainStep) against the eager loop it replaces
+(trainer.train_step; upstream trainer.py:165-179): same kernels in the same order on the same data, so -- with the
+dropout probabilities set to zero, the only source of run-to-run randomness -- the losses of every iteration and the
+final weights must be IDENTICAL, across a learning-rate change and a ragged batch shape."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _no_dropout(model):
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.GRU):
+            m.dropout = 0.0
+        if hasattr(m, "dropout_p"):
+            m.dropout_p = 0.0
+    return model
+
+
+def _batches(device, n, batch, channels=4, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for i in range(n):
+        b = batch if i % 7 != 6 else max(1, batch - 3)                         # every 7th batch is ragged (own graph)
+        x = (torch.randn(b, 250, channels, 64, generator=g) * 20 - 30).to(device)
+        m = ((torch.rand(b, 250, 648, generator=g) < 0.02).to(torch.int32) << 3).to(torch.uint16).to(device)
+        out.append((x, m))
+    return out
+
+
+def _train(kind, device, graphs, batches, lr_change_at=None):
+    import trainer
+    cfg = trainer.config
+    saved = (cfg.MODEL_TYPE, cfg.GRAPH_STEP)
+    cfg.MODEL_TYPE, cfg.GRAPH_STEP = kind, graphs
+    try:
+        torch.manual_seed(0)
+        model = _no_dropout(trainer.prepare_model_for_device(trainer.build_model((18, 36)), device)).train()
+        trainer.enable_master_weights(model, device)
+        crit = trainer.SMRSELDLoss("mse", 1.0, grid_size=(18, 36))
+        graphed = trainer.graph_step_enabled(device)
+        assert graphed == graphs
+        opt = trainer.make_optimizer(model, 1e-3, device, capturable=graphed)
+        step = trainer.make_stepper(model, crit, opt, device)
+        losses = []
+        for i, (x, m) in enumerate(batches):
+            if lr_change_at is not None and i == lr_change_at:
+                opt.param_groups[0]["lr"] = 2.5e-4                             # what ReduceLROnPlateau does: a float
+            total, _ = step(x, m)
+            losses.append(total.clone())
+        losses = torch.stack(losses).cpu()
+        stats = step.stats() if hasattr(step, "stats") else None
+        if hasattr(step, "close"):
+            step.close()
+        sd = {k: v.detach().float().cpu().clone() for k, v in trainer.model_state_dict(model).items()}
+        return losses, sd, stats
+    finally:
+        cfg.MODEL_TYPE, cfg.GRAPH_STEP = saved
+
+
+def test_crnn_graph_replay_is_bit_identical_to_the_eager_loop(gpu_device):
+    batches = _batches(gpu_device, 60, 8)
+    eager, sd_e, stats_e = _train("crnn", gpu_device, False, batches, lr_change_at=30)
+    graph, sd_g, stats = _train("crnn", gpu_device, True, batches, lr_change_at=30)
+    assert stats_e is None
+    assert stats["capture_error"] is None and stats["graphs"] == 2            # full batches + the ragged shape
+    assert stats["replays"] == 60 - stats["eager_iterations"] and stats["eager_iterations"] == 6   # 3 warm-ups per shape
+    assert torch.isfinite(eager).all() and eager[-1] < eager[0]
+    assert torch.equal(eager, graph), (eager - graph).abs().max().item()
+    for k in sd_e:
+        assert torch.equal(sd_e[k], sd_g[k]), k
+
+
+@pytest.mark.parametrize("kind", ["conformer", "resnet_conformer"])
+def test_other_models_capture_and_track_the_eager_loop(gpu_device, kind):
+    """The attention kernels' backward adds with atomics (run-to-run differences in the last bits): the captured loop
+    must track the eager one, not equal it."""
+    batches = _batches(gpu_device, 10, 2)
+    eager, _, _ = _train(kind, gpu_device, False, batches)
+    graph, _, stats = _train(kind, gpu_device, True, batches)
+    assert stats["capture_error"] is None and stats["graphs"] >= 1 and stats["replays"] >= 4
+    assert torch.isfinite(graph).all()
+    assert (eager - graph).abs().max().item() <= 2e-2 * eager.abs().max().item()
