@@ -93,8 +93,8 @@ class GraphedTrainStep:
         self.captured = self.replays = self.eager_calls = 0
         self.capture_error = None
         self._lr_tensors = []
-        if self.use_graphs:
-            for group in optimizer.param_groups:
+        if self.use_graphs or any(isinstance(g["lr"], torch.Tensor) for g in optimizer.param_groups):
+            for group in optimizer.param_groups:       # the learning rate as a device scalar (read by a capturable Adam)
                 lr = group["lr"]
                 t = lr if isinstance(lr, torch.Tensor) else torch.tensor(float(lr), dtype=torch.float32, device=device)
                 group["lr"] = t
@@ -124,9 +124,9 @@ class GraphedTrainStep:
 
     # ---- call ---------------------------------------------------------------------------------------------------
     def __call__(self, spec, labels):
+        self._sync_lr()
         if not self.use_graphs:
             return self._eager(spec, labels)
-        self._sync_lr()
         key = (tuple(spec.shape), spec.dtype, tuple(labels.shape), labels.dtype)
         st = self.shapes.get(key)
         if st is None:

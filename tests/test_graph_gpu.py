@@ -31,19 +31,21 @@ def _batches(device, n, batch, channels=4, seed=3):
 
 
 def _train(kind, device, graphs, batches, lr_change_at=None):
+    """``graphs`` False: the same stepper object run eagerly (same optimiser: capturable fused Adam, device-side
+    learning rate and step count -- the non-capturable Adam rounds the step size differently in the last bit)."""
+    import seld_graph
     import trainer
     cfg = trainer.config
-    saved = (cfg.MODEL_TYPE, cfg.GRAPH_STEP)
-    cfg.MODEL_TYPE, cfg.GRAPH_STEP = kind, graphs
+    saved = cfg.MODEL_TYPE
+    cfg.MODEL_TYPE = kind
     try:
         torch.manual_seed(0)
         model = _no_dropout(trainer.prepare_model_for_device(trainer.build_model((18, 36)), device)).train()
         trainer.enable_master_weights(model, device)
         crit = trainer.SMRSELDLoss("mse", 1.0, grid_size=(18, 36))
-        graphed = trainer.graph_step_enabled(device)
-        assert graphed == graphs
-        opt = trainer.make_optimizer(model, 1e-3, device, capturable=graphed)
-        step = trainer.make_stepper(model, crit, opt, device)
+        opt = trainer.make_optimizer(model, 1e-3, device, capturable=True)
+        step = seld_graph.GraphedTrainStep(model, crit, opt, device, autocast=lambda: trainer.autocast_context(device),
+                                           use_graphs=graphs)
         losses = []
         for i, (x, m) in enumerate(batches):
             if lr_change_at is not None and i == lr_change_at:
@@ -57,14 +59,14 @@ def _train(kind, device, graphs, batches, lr_change_at=None):
         sd = {k: v.detach().float().cpu().clone() for k, v in trainer.model_state_dict(model).items()}
         return losses, sd, stats
     finally:
-        cfg.MODEL_TYPE, cfg.GRAPH_STEP = saved
+        cfg.MODEL_TYPE = saved
 
 
 def test_crnn_graph_replay_is_bit_identical_to_the_eager_loop(gpu_device):
     batches = _batches(gpu_device, 60, 8)
     eager, sd_e, stats_e = _train("crnn", gpu_device, False, batches, lr_change_at=30)
     graph, sd_g, stats = _train("crnn", gpu_device, True, batches, lr_change_at=30)
-    assert stats_e is None
+    assert stats_e["graphs"] == 0 and stats_e["eager_iterations"] == 60
     assert stats["capture_error"] is None and stats["graphs"] == 2            # full batches + the ragged shape
     assert stats["replays"] == 60 - stats["eager_iterations"] and stats["eager_iterations"] == 6   # 3 warm-ups per shape
     assert torch.isfinite(eager).all() and eager[-1] < eager[0]
