@@ -210,8 +210,12 @@ class HotPath:
         last = None
         for lo in range(0, self.starts.numel(), BATCH):
             starts = self.starts[lo:lo + BATCH]
-            spec = nat.gather_windows(spec_tm, starts, WINDOW)
-            mask = nat.gather_windows(self.mask_tm, starts, WINDOW)
+            # straight into the captured step's input buffers once it has them (what trainer.DeviceFeed does)
+            static = getattr(self.stepper, "static_inputs", None)
+            bufs = static((len(starts), WINDOW, self.feature_channels, 64), torch.float32,
+                          (len(starts), WINDOW, 648), torch.uint16) if static is not None else None
+            spec = nat.gather_windows(spec_tm, starts, WINDOW, out=bufs[0] if bufs else None)
+            mask = nat.gather_windows(self.mask_tm, starts, WINDOW, out=bufs[1] if bufs else None)
             last, _ = self.stepper(spec, mask)
         if timed:
             m1.record()

@@ -159,6 +159,36 @@ int seld_layernorm_backward(const void* x, const void* dy, int is_bf16, int64_t 
  * GEMMs occupy every CU.  No upstream counterpart (the reference's trainer.py:165-179 is single-stream). */
 int seld_stream_delay(int64_t nanoseconds, void* stream);
 
+/* ---- glue kernels of the training iteration (csrc/glue.hip): each replaces a chain of 3-10 framework launches of a
+ * few microseconds (clone / fill / add / cast, fill + reduce + copy, slice copies, flip + copy) by one launch ---- */
+
+/* nn.GRU's biases (model_crnn.py:65-72) as the recurrence consumes them: gi_bias [2][3][H] (bf16 when out_is_bf16,
+ * else fp32) = b_ih + (r, z rows of b_hh), the bias of the input-projection GEMM; b_hn [2][H] fp32 = n rows of b_hh.
+ * b_ih, b_hh: [2][3H] fp32 (forward, reverse). */
+int seld_gru_fold_bias(const float* b_ih, const float* b_hh, int64_t H, void* gi_bias, int out_is_bf16, float* b_hn,
+                       void* stream);
+
+/* seld_gru_backward's per-tile bias sums `partial` [tiles][2][4][H] -> nn.GRU's bias gradients db_ih [2][3H] =
+ * (da_r, da_z, da_n) and db_hh [2][3H] = (da_r, da_z, da_n r), fp32, tiles added in a fixed order. */
+int seld_gru_bias_grads(const float* partial, int64_t tiles, int64_t H, float* db_ih, float* db_hh, void* stream);
+
+/* out[i] = sum over c of partial[c][i], i < count (fp32 accumulation, fixed order): the reduction behind a split-K
+ * weight-gradient product (the autograd dW = dY^T X of every nn.Linear, trainer.py:178).  partial [chunks][count] bf16
+ * or fp32, out [count] bf16 or fp32. */
+int seld_sum_chunks(const void* partial, int in_is_bf16, int64_t chunks, int64_t count, void* out, int out_is_bf16,
+                    void* stream);
+
+/* dW_hh [2][3H][H] of nn.GRU from the two chunked products the host forms over both directions at once:
+ * p_gi [chunks][2][3][H][2][H] = (da_r, da_z, da_n)^T h_prev, p_n [chunks][2][H][2][H] = (da_n r)^T h_prev; the blocks
+ * with matching directions (and, of p_gi, the r and z gates) are summed over the chunks and written in place. */
+int seld_gru_dwhh_finish(const void* p_gi, const void* p_n, int in_is_bf16, int64_t chunks, int64_t H, void* dw_hh,
+                         int out_is_bf16, void* stream);
+
+/* wt[i][o][2-r][2-s] = w[o][i][r][s] for 3x3 weights, both in channels-last memory (w: [O][3][3][I], wt: [I][3][3][O]):
+ * the weights with which the DATA gradient of a 3x3 / stride 1 / pad 1 convolution (model_crnn.py:5-17) is itself a
+ * forward convolution.  elem_bytes 2 (bf16) or 4. */
+int seld_conv_weight_flip_transpose(const void* w, int elem_bytes, int64_t O, int64_t I, void* wt, void* stream);
+
 /* ---- CNN block tail: BatchNorm2d -> ReLU -> MaxPool2d((1,2)) at model_crnn.py:5-17 (ConvBlock.forward) ---- */
 /* x: the convolution output in channels-last memory order = row-major [rows = B*T*F][C] (bf16 when is_bf16, else
  * fp32); the two frequency bins of a pooling pair are adjacent rows.  pool = 2: MaxPool2d((1,2)); pool = 1: no

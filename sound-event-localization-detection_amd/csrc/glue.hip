@@ -1,0 +1,220 @@
+// Small fused "glue" kernels of the training iteration (gfx950).
+//
+// After the hot kernels were written, a CRNN iteration still contained ~110 framework launches of 2-10 us each --
+// clone / fill / add / cast chains around the GRU biases, fill + reduce + copy triples behind every split-K weight
+// gradient, slice copies that assemble dW_hh, flip + copy pairs that build the transposed convolution weights
+// (profiles/r02_iteration_timeline_before.txt).  A dependent kernel boundary costs ~1.5-5 us on this chip whatever the
+// kernel does (MI355X_MICROARCH.md, "boundary"), so each chain is replaced by ONE launch here.  All of them move a few
+// hundred KB at most: latency-sized, not bandwidth-sized; they exist to remove boundaries.
+//
+// Reference lines they serve: nn.GRU's bias handling (model_crnn.py:65-72), the Linear / GRU weight gradients autograd
+// computes for trainer.py:178, the data gradient of the encoder's 3x3 convolutions (model_crnn.py:5-17).
+#include <hip/hip_bf16.h>
+
+#include "seld_common.h"
+
+namespace seld {
+
+namespace {
+
+constexpr int kGlueThreads = 256;
+
+__device__ __forceinline__ float load_as_float(const void* p, long i, bool bf16) {
+  return bf16 ? __uint_as_float(static_cast<unsigned>(static_cast<const unsigned short*>(p)[i]) << 16)
+              : static_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void store_from_float(void* p, long i, bool bf16, float v) {
+  if (bf16) static_cast<unsigned short*>(p)[i] = __bfloat16_as_ushort(__float2bfloat16(v));
+  else static_cast<float*>(p)[i] = v;
+}
+
+// gi_bias[d][g][u] = b_ih[d][g][u] + (g < 2 ? b_hh[d][g][u] : 0)   (the r / z recurrent biases commute with the
+// sigmoid argument: they ride on the input projection's bias);  b_hn[d][u] = b_hh[d][2][u]
+__global__ __launch_bounds__(kGlueThreads) void gru_fold_bias_kernel(const float* __restrict__ b_ih,
+                                                                     const float* __restrict__ b_hh, int h,
+                                                                     void* __restrict__ gi_bias, int out_bf16,
+                                                                     float* __restrict__ b_hn) {
+  const int i = blockIdx.x * kGlueThreads + threadIdx.x;            // over [2][3][h]
+  if (i >= 2 * 3 * h) return;
+  const int u = i % h, g = (i / h) % 3, d = i / (3 * h);
+  const float hh = b_hh[i];
+  store_from_float(gi_bias, i, out_bf16 != 0, b_ih[i] + (g < 2 ? hh : 0.0f));
+  if (g == 2) b_hn[d * h + u] = hh;
+}
+
+// The backward recurrence leaves per-tile sums of (da_r, da_z, da_n, da_n r) over (sequence, time):
+// partial[tile][d][4][h].  db_ih[d] = (r, z, n) ; db_hh[d] = (r, z, n r): nn.GRU's bias gradients, in a fixed order.
+__global__ __launch_bounds__(kGlueThreads) void gru_bias_grads_kernel(const float* __restrict__ partial, int tiles, int h,
+                                                                      float* __restrict__ db_ih,
+                                                                      float* __restrict__ db_hh) {
+  const int i = blockIdx.x * kGlueThreads + threadIdx.x;            // over [2][4][h]
+  if (i >= 2 * 4 * h) return;
+  const int u = i % h, slot = (i / h) % 4, d = i / (4 * h);
+  float s = 0.0f;
+  for (int t = 0; t < tiles; ++t) s += partial[static_cast<long>(t) * 2 * 4 * h + i];
+  if (slot < 2) {
+    db_ih[(d * 3 + slot) * h + u] = s;
+    db_hh[(d * 3 + slot) * h + u] = s;
+  } else if (slot == 2) {
+    db_ih[(d * 3 + 2) * h + u] = s;
+  } else {
+    db_hh[(d * 3 + 2) * h + u] = s;
+  }
+}
+
+// out[i] = sum_c partial[c][i]  (fp32 accumulation, fixed order): the reduction behind a split-K product
+template <int kVec>
+__global__ __launch_bounds__(kGlueThreads) void sum_chunks_kernel(const void* __restrict__ partial, int in_bf16,
+                                                                  int chunks, long count, void* __restrict__ out,
+                                                                  int out_bf16) {
+  const long i0 = (static_cast<long>(blockIdx.x) * kGlueThreads + threadIdx.x) * kVec;
+  if (i0 >= count) return;
+  float acc[kVec];
+#pragma unroll
+  for (int j = 0; j < kVec; ++j) acc[j] = 0.0f;
+  for (int c = 0; c < chunks; ++c) {
+    const long base = static_cast<long>(c) * count + i0;
+    if (kVec == 8 && in_bf16) {
+      const uint4 v = *reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(partial) + base);
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[2 * j] += __uint_as_float(w[j] << 16);
+        acc[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < kVec; ++j)
+        if (i0 + j < count) acc[j] += load_as_float(partial, base + j, in_bf16 != 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kVec; ++j)
+    if (i0 + j < count) store_from_float(out, i0 + j, out_bf16 != 0, acc[j]);
+}
+
+// dW_hh[d][g][u][k] from the two wasteful-but-well-shaped products the host forms (seld_gru._BiGRULayer.backward):
+//   p_gi[c][d][g][u][d'][k] = chunk c of  dgi^T h_prev      (g = 0..2; only d' == d and g < 2 are wanted)
+//   p_n [c][d][u][d'][k]    = chunk c of  (da_n r)^T h_prev (only d' == d)
+// summed over the chunks in fp32 and written straight into the parameter-shaped gradient.
+__global__ __launch_bounds__(kGlueThreads) void gru_dwhh_finish_kernel(const void* __restrict__ p_gi,
+                                                                       const void* __restrict__ p_n, int in_bf16,
+                                                                       int chunks, int h, void* __restrict__ dw_hh,
+                                                                       int out_bf16) {
+  const long i = static_cast<long>(blockIdx.x) * kGlueThreads + threadIdx.x;      // over [2][3][h][h]
+  const long total = 2L * 3 * h * h;
+  if (i >= total) return;
+  const int k = static_cast<int>(i % h), u = static_cast<int>((i / h) % h);
+  const int g = static_cast<int>((i / (static_cast<long>(h) * h)) % 3), d = static_cast<int>(i / (3L * h * h));
+  float s = 0.0f;
+  if (g < 2) {
+    const long per = 2L * 3 * h * 2 * h;
+    const long off = ((((static_cast<long>(d) * 3 + g) * h + u) * 2 + d) * h) + k;
+    for (int c = 0; c < chunks; ++c) s += load_as_float(p_gi, c * per + off, in_bf16 != 0);
+  } else {
+    const long per = 2L * h * 2 * h;
+    const long off = (((static_cast<long>(d) * h + u) * 2 + d) * h) + k;
+    for (int c = 0; c < chunks; ++c) s += load_as_float(p_n, c * per + off, in_bf16 != 0);
+  }
+  store_from_float(dw_hh, i, out_bf16 != 0, s);
+}
+
+// Transposed, flipped 3x3 weights for "data gradient as a forward convolution" (model_crnn._Conv3x3):
+//   wt[i][o][2-r][2-s] = w[o][i][r][s],  both tensors in channels-last memory: w is [O][3][3][I], wt is [I][3][3][O].
+template <typename T>
+__global__ __launch_bounds__(kGlueThreads) void conv_weight_flip_transpose_kernel(const T* __restrict__ w, int O, int I,
+                                                                                  T* __restrict__ wt) {
+  const long idx = static_cast<long>(blockIdx.x) * kGlueThreads + threadIdx.x;    // over wt memory [I][3][3][O]
+  const long total = static_cast<long>(O) * I * 9;
+  if (idx >= total) return;
+  const int o = static_cast<int>(idx % O);
+  const int rs = static_cast<int>((idx / O) % 9);
+  const int i = static_cast<int>(idx / (9L * O));
+  wt[idx] = w[(static_cast<long>(o) * 9 + (8 - rs)) * I + i];
+}
+
+}  // namespace
+
+}  // namespace seld
+
+extern "C" {
+
+int seld_gru_fold_bias(const float* b_ih, const float* b_hh, int64_t H, void* gi_bias, int out_is_bf16, float* b_hn,
+                       void* stream_) {
+  using namespace seld;
+  if (!current_state()) return kErrNotInitialised;
+  if (H <= 0 || !b_ih || !b_hh || !gi_bias || !b_hn) return fail(kErrInvalidArgument, "seld_gru_fold_bias: bad argument");
+  const int n = static_cast<int>(6 * H);
+  hipLaunchKernelGGL(gru_fold_bias_kernel, dim3((n + kGlueThreads - 1) / kGlueThreads), dim3(kGlueThreads), 0,
+                     static_cast<hipStream_t>(stream_), b_ih, b_hh, static_cast<int>(H), gi_bias, out_is_bf16, b_hn);
+  SELD_HIP_TRY(hipGetLastError());
+  return kOk;
+}
+
+int seld_gru_bias_grads(const float* partial, int64_t tiles, int64_t H, float* db_ih, float* db_hh, void* stream_) {
+  using namespace seld;
+  if (!current_state()) return kErrNotInitialised;
+  if (H <= 0 || tiles <= 0 || !partial || !db_ih || !db_hh)
+    return fail(kErrInvalidArgument, "seld_gru_bias_grads: bad argument");
+  const int n = static_cast<int>(8 * H);
+  hipLaunchKernelGGL(gru_bias_grads_kernel, dim3((n + kGlueThreads - 1) / kGlueThreads), dim3(kGlueThreads), 0,
+                     static_cast<hipStream_t>(stream_), partial, static_cast<int>(tiles), static_cast<int>(H), db_ih,
+                     db_hh);
+  SELD_HIP_TRY(hipGetLastError());
+  return kOk;
+}
+
+int seld_sum_chunks(const void* partial, int in_is_bf16, int64_t chunks, int64_t count, void* out, int out_is_bf16,
+                    void* stream_) {
+  using namespace seld;
+  if (!current_state()) return kErrNotInitialised;
+  if (chunks <= 0 || count <= 0 || !partial || !out) return fail(kErrInvalidArgument, "seld_sum_chunks: bad argument");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const bool wide = in_is_bf16 && count % 8 == 0 && (reinterpret_cast<uintptr_t>(partial) & 15) == 0;
+  if (wide) {
+    const long threads = count / 8;
+    hipLaunchKernelGGL(sum_chunks_kernel<8>, dim3(static_cast<unsigned>((threads + kGlueThreads - 1) / kGlueThreads)),
+                       dim3(kGlueThreads), 0, stream, partial, in_is_bf16, static_cast<int>(chunks),
+                       static_cast<long>(count), out, out_is_bf16);
+  } else {
+    hipLaunchKernelGGL(sum_chunks_kernel<1>, dim3(static_cast<unsigned>((count + kGlueThreads - 1) / kGlueThreads)),
+                       dim3(kGlueThreads), 0, stream, partial, in_is_bf16, static_cast<int>(chunks),
+                       static_cast<long>(count), out, out_is_bf16);
+  }
+  SELD_HIP_TRY(hipGetLastError());
+  return kOk;
+}
+
+int seld_gru_dwhh_finish(const void* p_gi, const void* p_n, int in_is_bf16, int64_t chunks, int64_t H, void* dw_hh,
+                         int out_is_bf16, void* stream_) {
+  using namespace seld;
+  if (!current_state()) return kErrNotInitialised;
+  if (chunks <= 0 || H <= 0 || !p_gi || !p_n || !dw_hh) return fail(kErrInvalidArgument, "seld_gru_dwhh_finish: bad argument");
+  const long total = 6L * H * H;
+  hipLaunchKernelGGL(gru_dwhh_finish_kernel, dim3(static_cast<unsigned>((total + kGlueThreads - 1) / kGlueThreads)),
+                     dim3(kGlueThreads), 0, static_cast<hipStream_t>(stream_), p_gi, p_n, in_is_bf16,
+                     static_cast<int>(chunks), static_cast<int>(H), dw_hh, out_is_bf16);
+  SELD_HIP_TRY(hipGetLastError());
+  return kOk;
+}
+
+int seld_conv_weight_flip_transpose(const void* w, int elem_bytes, int64_t O, int64_t I, void* wt, void* stream_) {
+  using namespace seld;
+  if (!current_state()) return kErrNotInitialised;
+  if (O <= 0 || I <= 0 || !w || !wt) return fail(kErrInvalidArgument, "seld_conv_weight_flip_transpose: bad argument");
+  if (elem_bytes != 2 && elem_bytes != 4) return fail(kErrUnsupported, "seld_conv_weight_flip_transpose: 2- or 4-byte elements");
+  const long total = O * I * 9;
+  const dim3 grid(static_cast<unsigned>((total + kGlueThreads - 1) / kGlueThreads));
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (elem_bytes == 2)
+    hipLaunchKernelGGL(conv_weight_flip_transpose_kernel<unsigned short>, grid, dim3(kGlueThreads), 0, stream,
+                       static_cast<const unsigned short*>(w), static_cast<int>(O), static_cast<int>(I),
+                       static_cast<unsigned short*>(wt));
+  else
+    hipLaunchKernelGGL(conv_weight_flip_transpose_kernel<float>, grid, dim3(kGlueThreads), 0, stream,
+                       static_cast<const float*>(w), static_cast<int>(O), static_cast<int>(I), static_cast<float*>(wt));
+  SELD_HIP_TRY(hipGetLastError());
+  return kOk;
+}
+
+}  // extern "C"

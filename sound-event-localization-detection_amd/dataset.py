@@ -360,14 +360,21 @@ class SELDDataset(Dataset):
         return spec, torch.from_numpy(_expand_mask_host(mask, self.num_classes))
 
     # -- device feed (used by trainer when DEVICE_FEED is on) -----------------------------------
-    def device_batch(self, indices):
+    def device_batch(self, indices, out=None):
         """Window indices -> (spec [B, 250, C, 64] f32, mask [B, 250, 648] u16) on the device, gathered
-        by seld_window_gather straight from the device timeline (no host round trip, no dense labels)."""
+        by seld_window_gather straight from the device timeline (no host round trip, no dense labels).
+        ``out``: callable (spec_shape, spec_dtype, mask_shape, mask_dtype) -> (spec_buffer, mask_buffer) or None --
+        the static input buffers of a captured training step (seld_graph.GraphedTrainStep.static_inputs)."""
         if self.spec_tm is None:
             raise RuntimeError("device_batch needs keep_on_device=True")
         starts = torch.as_tensor(self.window_starts[np.asarray(indices, dtype=np.int64)])
-        spec = seld_native.gather_windows(self.spec_tm, starts, self.window_length_frames)
-        mask = seld_native.gather_windows(self.mask_tm, starts, self.window_length_frames)
+        w = self.window_length_frames
+        bufs = None
+        if out is not None:
+            bufs = out((len(starts), w) + tuple(self.spec_tm.shape[1:]), self.spec_tm.dtype,
+                       (len(starts), w) + tuple(self.mask_tm.shape[1:]), self.mask_tm.dtype)
+        spec = seld_native.gather_windows(self.spec_tm, starts, w, out=bufs[0] if bufs else None)
+        mask = seld_native.gather_windows(self.mask_tm, starts, w, out=bufs[1] if bufs else None)
         return spec, mask
 
 

@@ -112,7 +112,7 @@ class SMRSELDLoss(nn.Module):
     def loss_tensor(self, y_pred, y_true):
         """The scalar the optimiser differentiates, without the host sync of ``forward``'s breakdown."""
         term = self.class_mse_loss(y_pred, y_true) if self.loss_type == "mse" else self.class_ce_loss(y_pred, y_true)
-        return self.w_class * term, term
+        return (term if self.w_class == 1.0 else self.w_class * term), term      # no multiply (+ its backward) by 1
 
     def forward(self, y_pred: torch.Tensor, y_true: torch.Tensor):
         total, term = self.loss_tensor(y_pred, y_true)

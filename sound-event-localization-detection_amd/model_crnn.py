@@ -44,7 +44,11 @@ class _Conv3x3(torch.autograd.Function):
             dy = dy.to(xc.dtype).contiguous(memory_format=torch.channels_last)
             dx = None
             if ctx.needs_input_grad[0]:
-                wt = wc.transpose(0, 1).flip(2, 3).contiguous(memory_format=torch.channels_last)
+                if wc.is_contiguous(memory_format=torch.channels_last):
+                    import seld_native
+                    wt = seld_native.conv_weight_flip_transpose(wc)                 # one launch (flip + copy are two)
+                else:
+                    wt = wc.transpose(0, 1).flip(2, 3).contiguous(memory_format=torch.channels_last)
                 dx = F.conv2d(dy, wt, padding=1)
                 if dx.dtype != x_dtype:
                     dx = dx.to(x_dtype)
@@ -103,7 +107,9 @@ def run_cnn_blocks(blocks, x):
     """[B, T, C, F] -> [B, C_out, T, F_out] (channels-last memory on a GPU)."""
     x = x.permute(0, 2, 1, 3)
     if x.is_cuda:
-        x = x.contiguous(memory_format=torch.channels_last)
+        # one copy does the layout change AND the cast the first convolution would otherwise do under autocast
+        dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() and x.is_floating_point() else x.dtype
+        x = x.to(dtype=dtype, memory_format=torch.channels_last)
     for block in blocks:
         x = block(x)
     return x
@@ -153,7 +159,7 @@ class SELD_CRNN(nn.Module):
                 if overlap:
                     seld_overlap.defer_linear(self.fnn[0], self.fnn[4])
                 feats, _ = seld_gru.bigru_forward(self.rnn, feats_fc, feature_cf=(y.shape[1], y.shape[3]),
-                                                  overlap=overlap)
+                                                  overlap=overlap, need_hn=False)
                 return run_head(self.fnn, feats).view(batch, frames, self.grid_cells, self.num_classes)
         feats = y.permute(0, 2, 1, 3).reshape(batch, frames, -1)                # (channel, frequency) order
         feats, _ = self.rnn(feats)

@@ -9,7 +9,7 @@ input shape and replayed: the host then enqueues two window gathers and one grap
 
 Data parallel (world > 1): the iteration is cut at its one exchange step,
 
-    graph A  forward + loss + backward  ->  gradients accumulate into ONE flat buffer per dtype
+    graph A  forward + loss + backward  ->  gradients gathered into ONE flat buffer per dtype
     eager    all-reduce of the flat buffers (RCCL over xGMI; gloo in the rehearsal mode)
     graph B  1/world scaling, gradient casts, fused Adam, working-copy refresh
 
@@ -36,19 +36,22 @@ def _unwrap(model):
 
 
 class FlatGradients:
-    """``p.grad`` of every trainable parameter as a view into one contiguous buffer per dtype (bf16 working weights,
-    fp32 everything else): zeroed with one launch per buffer, all-reduced with one collective per buffer."""
+    """One contiguous buffer per gradient dtype (bf16 working weights, fp32 everything else) for the data-parallel
+    exchange: after the backward pass the gradients autograd produced are gathered into it by one multi-tensor copy per
+    dtype, the buffers are all-reduced (one collective each) and ``p.grad`` is pointed at the buffer's views, which the
+    optimiser then reads.  Only built for world > 1: a single rank hands autograd's tensors to the optimiser as they
+    are (no accumulation, no copy)."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         by_dtype = {}
         for p in self.params:
             by_dtype.setdefault(p.dtype, []).append(p)
-        self.buffers = []
+        self.buffers, self.groups = [], []
         for dtype, group in by_dtype.items():
             total = sum((p.numel() + 7) // 8 * 8 for p in group)          # 16-byte aligned pieces (vector kernels)
             flat = torch.zeros(total, dtype=dtype, device=group[0].device)
-            offset = 0
+            views, offset = [], 0
             for p in group:
                 n = p.numel()
                 view = flat[offset:offset + n]
@@ -57,13 +60,24 @@ class FlatGradients:
                     view = view.view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2)
                 else:
                     view = view.view(p.shape)
-                p.grad = view
+                views.append(view)
                 offset += (n + 7) // 8 * 8
             self.buffers.append(flat)
+            self.groups.append((group, views))
 
-    def zero(self):
-        for flat in self.buffers:
-            flat.zero_()
+    def gather(self):
+        """autograd's gradients -> the flat buffers; afterwards ``p.grad`` IS the buffer's view."""
+        for group, views in self.groups:
+            grads = []
+            for p, v in zip(group, views):
+                if p.grad is None:                    # a parameter the loss does not reach: contributes zeros
+                    v.zero_()
+                    grads.append(v)
+                else:
+                    grads.append(p.grad)
+            torch._foreach_copy_(views, grads)
+            for p, v in zip(group, views):
+                p.grad = v
 
     def scale(self, factor):
         for flat in self.buffers:
@@ -72,10 +86,6 @@ class FlatGradients:
     def all_reduce(self):
         for flat in self.buffers:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-
-    def detach_from(self):
-        for p in self.params:
-            p.grad = None
 
 
 class GraphedTrainStep:
@@ -87,7 +97,8 @@ class GraphedTrainStep:
         self.device, self.world = device, world
         self.autocast = autocast if autocast is not None else nullcontext
         self.use_graphs = bool(use_graphs) and device.type == "cuda"
-        self.flat = FlatGradients(_unwrap(model).parameters())
+        self.params = [p for p in _unwrap(model).parameters() if p.requires_grad]
+        self.flat = FlatGradients(self.params) if world > 1 else None
         self.shapes = {}             # key -> dict(calls, spec, labels, graph_a, graph_b, out)
         self.pool = None
         self.captured = self.replays = self.eager_calls = 0
@@ -102,11 +113,14 @@ class GraphedTrainStep:
 
     # ---- the two halves of an iteration (eager and captured runs execute exactly this code) ----------------------
     def _forward_backward(self, spec, labels):
-        self.flat.zero()
+        for p in self.params:                # autograd hands its gradient tensors over (no accumulate kernels); under
+            p.grad = None                    # capture they land in the graph's pool and are rewritten by every replay
         with self.autocast():
             predictions = self.model(spec)
         total, term = self.criterion.loss_tensor(predictions, labels)
         total.backward()
+        if self.flat is not None:
+            self.flat.gather()
         return total.detach(), term.detach()
 
     def _update(self):
@@ -142,8 +156,10 @@ class GraphedTrainStep:
                 logger.warning(f"HIP graph capture of the training step failed, running eagerly: {self.capture_error}")
                 torch.cuda.synchronize(self.device)
                 return self._eager(spec, labels)
-        st["spec"].copy_(spec, non_blocking=True)
-        st["labels"].copy_(labels, non_blocking=True)
+        if spec.data_ptr() != st["spec"].data_ptr():           # a feed that gathers straight into the static
+            st["spec"].copy_(spec, non_blocking=True)           # buffers (static_inputs) skips these two copies
+        if labels.data_ptr() != st["labels"].data_ptr():
+            st["labels"].copy_(labels, non_blocking=True)
         st["graph_a"].replay()
         if st["graph_b"] is not None:
             self.flat.all_reduce()
@@ -178,6 +194,14 @@ class GraphedTrainStep:
         st["graph_a"], st["graph_b"], st["out"] = graph_a, graph_b, out
         self.captured += 1
 
+    def static_inputs(self, spec_shape, spec_dtype, labels_shape, labels_dtype):
+        """The captured graph's input buffers for a batch of this shape, or None while that shape still runs eagerly:
+        a feed may gather its batch directly into them (``seld_native.gather_windows(..., out=)``)."""
+        st = self.shapes.get((tuple(spec_shape), spec_dtype, tuple(labels_shape), labels_dtype))
+        if st is None or st.get("graph_a") is None:
+            return None
+        return st["spec"], st["labels"]
+
     def stats(self):
         return {"graphs": self.captured, "replays": self.replays, "eager_iterations": self.eager_calls,
                 "capture_error": self.capture_error}
@@ -185,4 +209,5 @@ class GraphedTrainStep:
     def close(self):
         """Drop the graphs and hand the parameters ordinary (absent) gradients again."""
         self.shapes.clear()
-        self.flat.detach_from()
+        for p in self.params:
+            p.grad = None

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 import seld_native
 import seld_overlap
-from seld_linear import tall_product
+from seld_linear import chunk_count, tall_chunks, tall_product
 
 HIDDEN = 256
 
@@ -37,13 +37,17 @@ class _BiGRULayer(torch.autograd.Function):
         cdt = torch.bfloat16 if low else torch.float32
         with torch.autocast(device_type="cuda", enabled=False):
             xc = x.to(cdt)
-            # the r / z recurrent biases commute with the sigmoid argument: fold them into the GEMM's bias
-            fold = b_hh.clone()
-            fold[:, 2 * HIDDEN:] = 0
-            gi = F.linear(xc, w_ih.to(cdt), (b_ih + fold.reshape(-1)).to(cdt))   # [B, T, 6H]
+            # the r / z recurrent biases commute with the sigmoid argument: they ride on the GEMM's bias
+            if b_ih.dtype == torch.float32 and b_hh.dtype == torch.float32 and b_ih.is_contiguous() and b_hh.is_contiguous():
+                gi_bias, b_hn = seld_native.gru_fold_bias(b_ih, b_hh.reshape(-1), cdt)        # one launch
+            else:
+                fold = b_hh.clone()
+                fold[:, 2 * HIDDEN:] = 0
+                gi_bias, b_hn = (b_ih + fold.reshape(-1)).to(cdt), b_hh[:, 2 * HIDDEN:]
+            gi = F.linear(xc, w_ih.to(cdt), gi_bias)                               # [B, T, 6H]
             b, t, _ = gi.shape
             need = x.requires_grad or w_ih.requires_grad or w_hh.requires_grad
-            y, saved = seld_native.gru_forward(gi.view(b, t, 2, 3 * HIDDEN), w_hh, b_hh[:, 2 * HIDDEN:], need)
+            y, saved = seld_native.gru_forward(gi.view(b, t, 2, 3 * HIDDEN), w_hh, b_hn, need)
         ctx.save_for_backward(xc, w_ih, w_hh, y, saved if saved is not None else torch.empty(0))
         ctx.cdt = cdt
         ctx.dtypes = (w_ih.dtype, b_ih.dtype, w_hh.dtype, b_hh.dtype)
@@ -60,7 +64,7 @@ class _BiGRULayer(torch.autograd.Function):
             dyc = dy.to(y.dtype)
             # weight-gradient jobs queued by the layers above start now, beside this recurrence (seld_overlap)
             seld_overlap.launch_pending(dy.device)
-            dgi, dghn, dbias = seld_native.gru_backward(dyc, saved, y, w_hh)
+            dgi, dghn, dbias = seld_native.gru_backward(dyc, saved, y, w_hh, raw_bias=True)
             dgi2 = dgi.view(n, 6 * h)                                             # d/d(gi), both directions
             x2 = xc.reshape(n, -1)
             t_wih, t_bih, t_whh, t_bhh = ctx.dtypes
@@ -75,12 +79,11 @@ class _BiGRULayer(torch.autograd.Function):
                 # d/d(gh) = (da_r, da_z, da_n * r).  Two well-shaped products instead of eight skinny ones: all of
                 # dgi and dghn against both directions' h_prev; the wanted blocks are those with matching directions
                 # (the cross-direction blocks and dgi's n rows are computed and dropped: ~6 GFLOP, cheaper than the
-                # launches).
-                p_gi = tall_product(dgi2, hp, out_dtype=t_whh).view(2, 3, h, 2, h)   # [dir, gate, unit, dir', unit']
-                p_n = tall_product(dghn.view(n, 2 * h), hp, out_dtype=t_whh).view(2, h, 2, h)
-                for d in range(2):
-                    dw_hh[d, :2 * h].view(2, h, h).copy_(p_gi[d, :2, :, d])
-                    dw_hh[d, 2 * h:].copy_(p_n[d, :, d])
+                # launches).  The chunk sums and the block extraction are one kernel (seld_gru_dwhh_finish).
+                chunks = chunk_count(n, 6 * h, 2 * h)
+                p_gi = tall_chunks(dgi2, hp, chunks)                                # [chunks, (dir, gate, unit), (dir', unit')]
+                p_n = tall_chunks(dghn.view(n, 2 * h), hp, chunks)                  # [chunks, (dir, unit), (dir', unit')]
+                seld_native.gru_dwhh_finish(p_gi, p_n, dw_hh)
 
             dx = (dgi2 @ w_ih.to(cdt)).view_as(xc)
             if ctx.overlap:
@@ -88,8 +91,8 @@ class _BiGRULayer(torch.autograd.Function):
                 seld_overlap.submit(dy.device, [dgi, dghn, y, xc, dw_ih, dw_hh], weight_grads)
             else:
                 weight_grads()
-            db_ih = dbias[:, :3].reshape(-1)
-            db_hh = torch.cat((dbias[:, :2], dbias[:, 3:]), dim=1).reshape(2, 3 * h)
+            db_ih, db_hh = seld_native.gru_bias_grads(dbias)                       # [6H], [6H] fp32, one launch
+            db_hh = db_hh.view(2, 3 * h)
         return dx.to(dy.dtype) if dx.dtype != dy.dtype and not torch.is_autocast_enabled() else dx, \
             dw_ih, db_ih.to(t_bih), dw_hh, db_hh.to(t_bhh), None
 
@@ -136,8 +139,9 @@ def pack_parameters(module):
                 b.data = flat[a.numel():].view_as(b)
 
 
-def bigru_forward(module, x, feature_cf=None, overlap=False):
-    """Drop-in for ``nn.GRU.forward(x)`` with h0 = 0: returns (output [B,T,2H], h_n [2*layers,B,H]).
+def bigru_forward(module, x, feature_cf=None, overlap=False, need_hn=True):
+    """Drop-in for ``nn.GRU.forward(x)`` with h0 = 0: returns (output [B,T,2H], h_n [2*layers,B,H]; None unless
+    ``need_hn`` -- the CRNN never looks at it and the stack is one more launch).
     ``feature_cf = (C, F)``: the input features are ordered (frequency, channel) -- f * C + c -- instead of the
     parameters' (channel, frequency) order c * F + f; layer 0's W_ih columns are permuted to match.
     ``overlap``: weight gradients of layers >= 1 on the side stream (seld_overlap)."""
@@ -160,7 +164,8 @@ def bigru_forward(module, x, feature_cf=None, overlap=False):
             w_ih = w_ih.view(w_ih.shape[0], c, f).transpose(1, 2).reshape(w_ih.shape[0], f * c)
         out = _BiGRULayer.apply(out, w_ih, b_ih, w_hh.view(2, 3 * HIDDEN, HIDDEN), b_hh.view(2, 3 * HIDDEN),
                                 overlap and layer > 0)
-        finals += [out[:, -1, :HIDDEN], out[:, 0, HIDDEN:]]
+        if need_hn:
+            finals += [out[:, -1, :HIDDEN], out[:, 0, HIDDEN:]]
         if module.training and module.dropout > 0 and layer + 1 < module.num_layers:
             out = F.dropout(out, p=module.dropout, training=True)
-    return out, torch.stack(finals, dim=0)
+    return out, (torch.stack(finals, dim=0) if need_hn else None)

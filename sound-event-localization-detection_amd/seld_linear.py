@@ -25,20 +25,40 @@ def tall_product(a, c, out_dtype=torch.float32, out=None):
     that accumulates in fp32 and writes ``out_dtype`` directly (into ``out`` if given)."""
     n, g = a.shape
     k = c.shape[1]
-    tiles = ((g + 127) // 128) * ((k + 127) // 128)
-    chunks = 5 if tiles >= 150 else 8
-    while chunks > 1 and (n % chunks or n // chunks < 256):
-        chunks -= 1
+    chunks = chunk_count(n, g, k)
     if chunks == 1:
         prod = a.t() @ c
         if out is not None:
             return out.copy_(prod)
         return prod if prod.dtype == out_dtype else prod.to(out_dtype)
+    partial = tall_chunks(a, c, chunks)                                           # [chunks, G, K]
+    if out is None:
+        out = torch.empty((g, k), dtype=out_dtype, device=a.device)
+    if partial.is_cuda and out.is_contiguous() and partial.dtype in (torch.float32, torch.bfloat16) \
+            and out.dtype in (torch.float32, torch.bfloat16):
+        import seld_native
+        return seld_native.sum_chunks(partial, out)          # one launch (torch.sum(out=) is fill + reduce + copy)
+    return torch.sum(partial, dim=0, dtype=out.dtype, out=out)
+
+
+def chunk_count(n, g, k):
+    """Row chunks for ``tall_chunks`` (from tools/bench_tall_product.py): 5 when the output has >= 150 tiles of 128 x 128,
+    else 8; reduced until it divides n with at least 256 rows per chunk."""
+    tiles = ((g + 127) // 128) * ((k + 127) // 128)
+    chunks = 5 if tiles >= 150 else 8
+    while chunks > 1 and (n % chunks or n // chunks < 256):
+        chunks -= 1
+    return chunks
+
+
+def tall_chunks(a, c, chunks=None):
+    """The partial products of ``tall_product``: [chunks, G, K] in the operands' dtype, ONE batched GEMM on views."""
+    n = a.shape[0]
+    if chunks is None:
+        chunks = chunk_count(n, a.shape[1], c.shape[1])
     av = a.unflatten(0, (chunks, n // chunks)).transpose(1, 2)                    # [chunks, G, N/chunks] view
     cv = c.unflatten(0, (chunks, n // chunks))
-    if out is not None:
-        return torch.sum(torch.bmm(av, cv), dim=0, dtype=out.dtype, out=out)
-    return torch.sum(torch.bmm(av, cv), dim=0, dtype=out_dtype)
+    return torch.bmm(av, cv)
 
 
 class _Linear(torch.autograd.Function):
@@ -78,14 +98,12 @@ class _Linear(torch.autograd.Function):
                     if dw is not None:
                         tall_product(g2, x2, out=dw)
                     if db is not None:
-                        db.copy_(torch.sum(g2, dim=0, dtype=torch.float32))
+                        torch.sum(g2, dim=0, dtype=db.dtype, out=db)     # fp32 accumulation inside the reduction
 
                 seld_overlap.submit(grad.device, [t for t in (g2, x2, dw, db) if t is not None], job)
             else:
                 dw = tall_product(g2, x2, out_dtype=ctx.w_dtype) if want_w else None
-                db = torch.sum(g2, dim=0, dtype=torch.float32) if want_b else None
-                if db is not None and db.dtype != ctx.b_dtype:
-                    db = db.to(ctx.b_dtype)
+                db = torch.sum(g2, dim=0, dtype=ctx.b_dtype) if want_b else None     # accumulates in fp32
         if dx is not None and dx.dtype != ctx.in_dtype:
             dx = dx.to(ctx.in_dtype)
         return dx, dw, db, None

@@ -66,6 +66,11 @@ def _declare(lib):
     lib.seld_scale_by_device_scalar.argtypes = [_ptr, _int, _i64, _ptr, _ptr]
     lib.seld_multi_cast.argtypes = [_ptr, _ptr, _ptr, _int, _int, _ptr]
     lib.seld_stream_delay.argtypes = [_i64, _ptr]
+    lib.seld_gru_fold_bias.argtypes = [_ptr, _ptr, _i64, _ptr, _int, _ptr, _ptr]
+    lib.seld_gru_bias_grads.argtypes = [_ptr, _i64, _i64, _ptr, _ptr, _ptr]
+    lib.seld_sum_chunks.argtypes = [_ptr, _int, _i64, _i64, _ptr, _int, _ptr]
+    lib.seld_gru_dwhh_finish.argtypes = [_ptr, _ptr, _int, _i64, _i64, _ptr, _int, _ptr]
+    lib.seld_conv_weight_flip_transpose.argtypes = [_ptr, _int, _i64, _i64, _ptr, _ptr]
     lib.seld_layernorm_supported.argtypes = [_i64]
     lib.seld_layernorm_workspace_floats.restype = _i64
     lib.seld_layernorm_workspace_floats.argtypes = [_i64, _i64]
@@ -684,9 +689,10 @@ def gru_forward(gi: torch.Tensor, w_hh: torch.Tensor, b_hn: torch.Tensor, need_s
     return y[:b], saved
 
 
-def gru_backward(dy: torch.Tensor, saved: torch.Tensor, y: torch.Tensor, w_hh: torch.Tensor):
+def gru_backward(dy: torch.Tensor, saved: torch.Tensor, y: torch.Tensor, w_hh: torch.Tensor, raw_bias: bool = False):
     """dy [B, T, 2H], the forward's (saved, y) -> (dgi [B, T, 2, 3, H] = (da_r, da_z, da_n), dghn [B, T, 2, H] =
-    da_n*r, both of dy's dtype, dbias [2, 4, H] fp32 = the four slots summed over batch and time)."""
+    da_n*r, both of dy's dtype, dbias [2, 4, H] fp32 = the four slots summed over batch and time; with ``raw_bias``
+    the per-tile sums [tiles, 2, 4, H] as the kernel left them, for ``gru_bias_grads``)."""
     b, t, h2 = dy.shape
     h = h2 // 2
     index = ensure_init(dy.device)
@@ -708,7 +714,83 @@ def gru_backward(dy: torch.Tensor, saved: torch.Tensor, y: torch.Tensor, w_hh: t
                                                _p(w_t), tiles, t, h, _p(dg_tile), _p(dbias), _stream_ptr(dy.device)),
               "seld_gru_backward")
     dgi, dghn = from_pair_tile_device(dg_tile, b)
+    if raw_bias:
+        return dgi, dghn, dbias
     return dgi, dghn, dbias.sum(dim=0) if tiles > 1 else dbias[0]
+
+
+# --------------------------------------------------------------------------- glue kernels (csrc/glue.hip)
+
+def _is_bf16(t: torch.Tensor) -> int:
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"float32 or bfloat16 expected, got {t.dtype}")
+    return int(t.dtype == torch.bfloat16)
+
+
+def gru_fold_bias(b_ih: torch.Tensor, b_hh: torch.Tensor, dtype: torch.dtype):
+    """b_ih, b_hh: fp32 [2*3H] (forward rows, then reverse) -> (gi_bias [6H] in ``dtype`` = b_ih + the r / z rows of b_hh,
+    b_hn [2, H] fp32): one launch instead of clone, fill, add, cast, slice-copy."""
+    if not (b_ih.is_cuda and b_ih.dtype == torch.float32 and b_hh.dtype == torch.float32 and b_ih.is_contiguous()
+            and b_hh.is_contiguous() and b_ih.numel() == b_hh.numel() and b_ih.numel() % 6 == 0):
+        raise SeldNativeError("gru_fold_bias: b_ih, b_hh must be contiguous fp32 GPU tensors of 2 * 3H elements")
+    h = b_ih.numel() // 6
+    gi_bias = torch.empty(6 * h, dtype=dtype, device=b_ih.device)
+    b_hn = torch.empty((2, h), dtype=torch.float32, device=b_ih.device)
+    with _device_guard(ensure_init(b_ih.device)):
+        check(load_library().seld_gru_fold_bias(_p(b_ih), _p(b_hh), h, _p(gi_bias), _is_bf16(gi_bias), _p(b_hn),
+                                                _stream_ptr(b_ih.device)), "seld_gru_fold_bias")
+    return gi_bias, b_hn
+
+
+def gru_bias_grads(partial: torch.Tensor):
+    """The backward recurrence's per-tile sums [tiles, 2, 4, H] fp32 -> (db_ih [2*3H], db_hh [2*3H]) fp32."""
+    tiles, two, four, h = partial.shape
+    if two != 2 or four != 4 or partial.dtype != torch.float32 or not partial.is_contiguous():
+        raise SeldNativeError("gru_bias_grads: partial must be contiguous fp32 [tiles, 2, 4, H]")
+    db = torch.empty((2, 6 * h), dtype=torch.float32, device=partial.device)
+    with _device_guard(ensure_init(partial.device)):
+        check(load_library().seld_gru_bias_grads(_p(partial), tiles, h, _p(db[0]), _p(db[1]),
+                                                 _stream_ptr(partial.device)), "seld_gru_bias_grads")
+    return db[0], db[1]
+
+
+def sum_chunks(partial: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[...] = partial.sum(dim=0) accumulated in fp32 (partial [chunks, ...] contiguous bf16 / fp32; out contiguous)."""
+    if not (partial.is_cuda and partial.is_contiguous() and out.is_contiguous()
+            and tuple(partial.shape[1:]) == tuple(out.shape)):
+        raise SeldNativeError("sum_chunks: partial [chunks, ...] and out [...] must be contiguous with matching shapes")
+    with _device_guard(ensure_init(partial.device)):
+        check(load_library().seld_sum_chunks(_p(partial), _is_bf16(partial), partial.shape[0], out.numel(), _p(out),
+                                             _is_bf16(out), _stream_ptr(partial.device)), "seld_sum_chunks")
+    return out
+
+
+def gru_dwhh_finish(p_gi: torch.Tensor, p_n: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """p_gi [chunks, 6H, 2H], p_n [chunks, 2H, 2H] (chunked products against both directions' h_prev) -> out [2, 3H, H]."""
+    chunks = p_gi.shape[0]
+    h = out.shape[2]
+    if not (p_gi.is_contiguous() and p_n.is_contiguous() and out.is_contiguous() and p_gi.dtype == p_n.dtype
+            and tuple(p_gi.shape) == (chunks, 6 * h, 2 * h) and tuple(p_n.shape) == (chunks, 2 * h, 2 * h)
+            and tuple(out.shape) == (2, 3 * h, h)):
+        raise SeldNativeError("gru_dwhh_finish: shapes must be [chunks, 6H, 2H], [chunks, 2H, 2H] -> [2, 3H, H]")
+    with _device_guard(ensure_init(out.device)):
+        check(load_library().seld_gru_dwhh_finish(_p(p_gi), _p(p_n), _is_bf16(p_gi), chunks, h, _p(out), _is_bf16(out),
+                                                  _stream_ptr(out.device)), "seld_gru_dwhh_finish")
+    return out
+
+
+def conv_weight_flip_transpose(w: torch.Tensor) -> torch.Tensor:
+    """w [O, I, 3, 3] in channels-last memory -> [I, O, 3, 3] in channels-last memory with wt[i,o,r,s] = w[o,i,2-r,2-s]
+    (= ``w.transpose(0, 1).flip(2, 3).contiguous(memory_format=torch.channels_last)`` in one launch)."""
+    o, i, kh, kw = w.shape
+    if not (w.is_cuda and kh == 3 and kw == 3 and w.dtype in (torch.float32, torch.bfloat16)
+            and w.is_contiguous(memory_format=torch.channels_last)):
+        raise SeldNativeError("conv_weight_flip_transpose: 3x3 weights in channels-last memory expected")
+    wt = torch.empty((i, o, 3, 3), dtype=w.dtype, device=w.device).contiguous(memory_format=torch.channels_last)
+    with _device_guard(ensure_init(w.device)):
+        check(load_library().seld_conv_weight_flip_transpose(_p(w), w.element_size(), o, i, _p(wt),
+                                                             _stream_ptr(w.device)), "seld_conv_weight_flip_transpose")
+    return wt
 
 
 # --------------------------------------------------------------------------- STFT / spatial features

@@ -262,9 +262,10 @@ class DeviceFeed:
         n = len(shard_indices(range(len(self.dataset)), self.rank, self.world))
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
-    def batches(self, epoch):
+    def batches(self, epoch, out=None):
+        """``out``: see SELDDataset.device_batch (gather straight into a captured step's input buffers)."""
         for idx in batched(self._order(epoch), self.batch_size, self.drop_last):
-            yield self.dataset.device_batch(idx)
+            yield self.dataset.device_batch(idx, out=out)
 
 
 def make_feed(loader, device, rank, world):
@@ -311,7 +312,8 @@ def eval_step(model, criterion, spectrograms, labels, device):
 # autocast would produce from the fp32 masters -- and the optimiser owns the fp32 masters: per iteration ONE
 # multi-tensor copy of the bf16 gradients into the masters' fp32 gradients, fused Adam on the masters, ONE
 # multi-tensor copy back.  Under DDP the weight gradients are then all-reduced in bf16 (half the xGMI bytes).
-# BatchNorm / LayerNorm parameters and all biases stay fp32 (autocast keeps those ops in fp32 as well).
+# BatchNorm / LayerNorm parameters and the GRU / convolution biases stay fp32 (autocast keeps those ops in fp32 as well);
+# nn.Linear biases are working copies too (the GEMM epilogue adds them in the compute dtype either way).
 
 def enable_master_weights(model, device):
     """Convert in place; returns True when active.  Call before wrap_ddp / make_optimizer."""
@@ -325,7 +327,10 @@ def enable_master_weights(model, device):
         if not isinstance(module, (torch.nn.Conv1d, torch.nn.Conv2d, torch.nn.Linear, torch.nn.GRU)):
             continue
         for pname, p in module.named_parameters(recurse=False):
-            if p.ndim >= 2 and p.dtype == torch.float32 and p.requires_grad:
+            # weight matrices, and the biases of Linear layers (they enter the GEMM epilogue in the compute dtype: a
+            # per-iteration cast otherwise); GRU / conv / norm biases stay fp32 (kernels that read them in fp32)
+            low = p.ndim >= 2 or (isinstance(module, torch.nn.Linear) and pname == "bias")
+            if low and p.dtype == torch.float32 and p.requires_grad:
                 master = p.detach().clone()
                 p.data = p.data.to(torch.bfloat16)
                 low.append(p)
@@ -503,7 +508,9 @@ def train_model(train_loader, test_loader, num_epochs=None, batch_size=None, lea
         loss_sum = torch.zeros((), dtype=torch.float64, device=device)
         term_sum = torch.zeros((), dtype=torch.float64, device=device)
         steps = 0
-        bar = tqdm(train_feed.batches(epoch), total=len(train_feed), desc=f"Epoch {epoch}/{num_epochs} [Train]",
+        static = getattr(stepper, "static_inputs", None) if isinstance(train_feed, DeviceFeed) else None
+        source = train_feed.batches(epoch, out=static) if static is not None else train_feed.batches(epoch)
+        bar = tqdm(source, total=len(train_feed), desc=f"Epoch {epoch}/{num_epochs} [Train]",
                    leave=False, disable=not is_main)
         for spectrograms, labels in bar:
             total, term = stepper(spectrograms, labels)
