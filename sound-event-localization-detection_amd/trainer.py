@@ -329,8 +329,8 @@ def enable_master_weights(model, device):
         for pname, p in module.named_parameters(recurse=False):
             # weight matrices, and the biases of Linear layers (they enter the GEMM epilogue in the compute dtype: a
             # per-iteration cast otherwise); GRU / conv / norm biases stay fp32 (kernels that read them in fp32)
-            low = p.ndim >= 2 or (isinstance(module, torch.nn.Linear) and pname == "bias")
-            if low and p.dtype == torch.float32 and p.requires_grad:
+            working = p.ndim >= 2 or (isinstance(module, torch.nn.Linear) and pname == "bias")
+            if working and p.dtype == torch.float32 and p.requires_grad:
                 master = p.detach().clone()
                 p.data = p.data.to(torch.bfloat16)
                 low.append(p)
