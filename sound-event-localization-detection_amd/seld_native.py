@@ -786,7 +786,7 @@ def conv_weight_flip_transpose(w: torch.Tensor) -> torch.Tensor:
     if not (w.is_cuda and kh == 3 and kw == 3 and w.dtype in (torch.float32, torch.bfloat16)
             and w.is_contiguous(memory_format=torch.channels_last)):
         raise SeldNativeError("conv_weight_flip_transpose: 3x3 weights in channels-last memory expected")
-    wt = torch.empty((i, o, 3, 3), dtype=w.dtype, device=w.device).contiguous(memory_format=torch.channels_last)
+    wt = torch.empty((i, o, 3, 3), dtype=w.dtype, device=w.device, memory_format=torch.channels_last)
     with _device_guard(ensure_init(w.device)):
         check(load_library().seld_conv_weight_flip_transpose(_p(w), w.element_size(), o, i, _p(wt),
                                                              _stream_ptr(w.device)), "seld_conv_weight_flip_transpose")
