@@ -371,6 +371,9 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs 
 // wavefront does the work of two "logical" wavefronts of the tile layout (w = 2 p, 2 p + 1) one after the other: the
 // gate math of the first half has no dependence on the MFMAs of the second, so the scheduler can issue it in the
 // MFMAs' shadow (an MFMA holds the SIMD's issue port for 8 of its 16 cycles).
+// RESULT (kept as an experiment behind SELD_GRU_FORWARD=4, not the default): hipcc issues the two halves strictly one
+// after the other (MFMAs, gate math, MFMAs, gate math -- the asm MFMAs are opaque to sched_group_barrier) and the
+// kernel is 36 % SLOWER than the 8-wavefront one, see seld_gru_forward.
 constexpr int kGru4Threads = 256;
 
 template <typename T, bool kSave>
@@ -880,9 +883,13 @@ int seld_gru_forward(const void* gi, int is_bf16, const void* w_hh_bf16, const f
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     lds_attr_set(st, kAttrGruForward);
   }
+  // SELD_GRU_FORWARD=4 selects the 4-wavefront all-register kernel (developer A/B).  Measured, B = 32, T = 250, same
+  // box, alternating processes: 8 wavefronts 1.15 us/step (289 us), 4 wavefronts 1.57 us/step (392 us): with ONE
+  // wavefront per SIMD nothing runs in the shadow of its own MFMAs or of its gate math -- the two co-resident
+  // wavefronts of the 8-wavefront kernel overlap each other's phases, which is worth more than the LDS weight reads cost.
   static const int variant = [] {
-    const char* v = getenv("SELD_GRU_FORWARD");          // "8": the 8-wavefront kernel (n-gate weights in LDS)
-    return v && v[0] == '8' ? 8 : 4;
+    const char* v = getenv("SELD_GRU_FORWARD");
+    return v && v[0] == '4' ? 4 : 8;
   }();
   if (variant == 4 && is_bf16) {          // (the fp32 instantiation of the 4-wavefront kernel spills: 8 wavefronts there)
     hipLaunchKernelGGL(gru_forward4_kernel<__hip_bfloat16>, grid, dim3(kGru4Threads), 0, stream, a);
