@@ -159,6 +159,18 @@ int seld_layernorm_backward(const void* x, const void* dy, int is_bf16, int64_t 
  * GEMMs occupy every CU.  No upstream counterpart (the reference's trainer.py:165-179 is single-stream). */
 int seld_stream_delay(int64_t nanoseconds, void* stream);
 
+/* The three-term SMR-SELD loss of smrl_seld_gaussian.py:946-1072 (loss.py:43-54, 56-146 on probabilities), value and
+ * gradient in one pass (csrc/loss3.hip):  total = w_class * MSE(softmax(logits), y) + w_aiur * AIUR + w_cl * CL.
+ * logits [frames][rows*cols][14] fp32 or bf16; labels as seld_softmax_mse (uint16 mask per cell, or dense fp32);
+ * rows x cols = the I x J DOA grid (18 x 36), at least 3 x 3 and at most 1024 cells.  loss_out4 (device) receives
+ * (total, mse, aiur, cl).  grad (nullable, dtype of logits) = d total / d logits for an upstream gradient of 1 (the AIUR
+ * term is argmax based and has none).  workspace: seld_smr_loss_workspace_bytes(frames, rows * cols) bytes.
+ * Deterministic (fixed-order double partial sums, integer event counts). */
+int64_t seld_smr_loss_workspace_bytes(int64_t frames, int64_t cells_per_frame);
+int seld_smr_loss(const void* logits, int logits_is_bf16, const uint16_t* mask, const float* dense_labels,
+                  int64_t frames, int rows, int cols, int num_classes, float w_class, float w_aiur, float w_cl,
+                  float* loss_out4, void* grad, void* workspace, void* stream);
+
 /* ---- glue kernels of the training iteration (csrc/glue.hip): each replaces a chain of 3-10 framework launches of a
  * few microseconds (clone / fill / add / cast, fill + reduce + copy, slice copies, flip + copy) by one launch ---- */
 

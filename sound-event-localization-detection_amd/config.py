@@ -113,6 +113,9 @@ class Config:
     FEATURE_SET = "logmel"      # 'logmel' (the reference) | 'logmel_iv' (FOA: + 3 intensity-vector channels) |
                                 # 'logmel_gcc' (MIC array: + C(C-1)/2 GCC-PHAT channels); the model's n_channels
                                 # follows the dataset (4 -> 7, 8 -> 36)
+    THREE_TERM_LOSS = False     # total = W_CLASS * class + W_AIUR * AIUR + W_CL * CL on probabilities, as
+                                # smrl_seld_gaussian.py:1058-1072 (BASELINE configs[4]: with GAUSSIAN_AUGMENT and the
+                                # ResNet50-Conformer); False = the modular loss.py, class term only (loss.py:158-166)
     GAUSSIAN_AUGMENT = False    # smrl_seld_gaussian.py:397-534 label augmentation (+-2 sigma box per source)
     GAUSSIAN_SIGMA_AZIMUTH = 5.0
     GAUSSIAN_SIGMA_ELEVATION = 5.0

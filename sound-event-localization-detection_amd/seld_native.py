@@ -64,6 +64,10 @@ def _declare(lib):
     lib.seld_softmax_mse_workspace_bytes.argtypes = []
     lib.seld_softmax_mse.argtypes = [_ptr, _int, _ptr, _ptr, _i64, _int, ctypes.c_float, _ptr, _ptr, _ptr, _ptr]
     lib.seld_scale_by_device_scalar.argtypes = [_ptr, _int, _i64, _ptr, _ptr]
+    lib.seld_smr_loss_workspace_bytes.restype = _i64
+    lib.seld_smr_loss_workspace_bytes.argtypes = [_i64, _i64]
+    lib.seld_smr_loss.argtypes = [_ptr, _int, _ptr, _ptr, _i64, _int, _int, _int, ctypes.c_float, ctypes.c_float,
+                                  ctypes.c_float, _ptr, _ptr, _ptr, _ptr]
     lib.seld_multi_cast.argtypes = [_ptr, _ptr, _ptr, _int, _int, _ptr]
     lib.seld_stream_delay.argtypes = [_i64, _ptr]
     lib.seld_gru_fold_bias.argtypes = [_ptr, _ptr, _i64, _ptr, _int, _ptr, _ptr]
@@ -380,6 +384,43 @@ def softmax_mse(logits: torch.Tensor, labels: torch.Tensor, grad_scale: float | 
                                               _p(_workspace(logits.device)), _stream_ptr(logits.device)),
               "seld_softmax_mse")
     return loss[0], grad
+
+
+def smr_loss(logits: torch.Tensor, labels: torch.Tensor, grid, w_class: float, w_aiur: float, w_cl: float,
+             want_grad: bool):
+    """smrl_seld_gaussian.py:946-1072 fused (csrc/loss3.hip).  logits [..., G, 14] with G = grid[0] * grid[1]; labels:
+    uint16 mask [..., G] or dense float32 [..., G, 14].  Returns (terms [4] fp32 = total, mse, aiur, cl; grad like logits
+    or None)."""
+    if not logits.is_cuda:
+        raise SeldNativeError("smr_loss: logits must be a GPU tensor")
+    if logits.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("smr_loss: logits must be float32 or bfloat16")
+    rows, cols = int(grid[0]), int(grid[1])
+    m = logits.shape[-1]
+    cells = rows * cols
+    if logits.dim() < 2 or logits.shape[-2] != cells:
+        raise ValueError(f"smr_loss: logits must be [..., {cells}, {m}] for a {rows} x {cols} grid")
+    logits = logits.contiguous()
+    frames = logits.numel() // (cells * m)
+    labels = labels.contiguous()
+    if labels.dtype == torch.uint16:
+        if labels.numel() != frames * cells:
+            raise ValueError("smr_loss: mask shape does not match logits")
+        mask_p, dense_p = _p(labels), None
+    else:
+        if labels.dtype != torch.float32 or labels.numel() != logits.numel():
+            raise ValueError("smr_loss: dense labels must be float32 with the logits' shape")
+        mask_p, dense_p = None, _p(labels)
+    index = ensure_init(logits.device)
+    lib = load_library()
+    out = torch.empty(4, dtype=torch.float32, device=logits.device)
+    grad = torch.empty_like(logits) if want_grad else None
+    ws = torch.empty(lib.seld_smr_loss_workspace_bytes(frames, cells), dtype=torch.uint8, device=logits.device)
+    with _device_guard(index):
+        check(lib.seld_smr_loss(_p(logits), int(logits.dtype == torch.bfloat16), mask_p, dense_p, frames, rows, cols, m,
+                                float(w_class), float(w_aiur), float(w_cl), _p(out), _p(grad), _p(ws),
+                                _stream_ptr(logits.device)), "seld_smr_loss")
+    return out, grad
 
 
 def scale_by_device_scalar_(data: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:

@@ -481,7 +481,8 @@ def train_model(train_loader, test_loader, num_epochs=None, batch_size=None, lea
     class_weights = torch.ones(config.NUM_CLASSES, device=device)
     class_weights[config.NUM_CLASSES - 1] = 0.05            # trainer.py:99-100
     criterion = SMRSELDLoss(loss_type=config.LOSS_TYPE, w_class=config.W_CLASS, w_aiur=config.W_AIUR,
-                            w_cl=config.W_CL, grid_size=grid, class_weights=class_weights)
+                            w_cl=config.W_CL, grid_size=grid, class_weights=class_weights,
+                            three_term=getattr(config, "THREE_TERM_LOSS", False))
     optimizer = make_optimizer(model, learning_rate, device, capturable=graphed)
     stepper = make_stepper(model, criterion, optimizer, device, world)
     scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=config.LR_DECAY_FACTOR,
@@ -654,7 +655,8 @@ def test_model(test_loader, model_path=None, batch_size=None, device=None, num_v
     model.eval()
     logger.info(f"Model loaded (epoch {checkpoint['epoch']}, test loss {checkpoint['test_loss']:.6f})")
     criterion = SMRSELDLoss(loss_type=config.LOSS_TYPE, w_class=config.W_CLASS, w_aiur=config.W_AIUR,
-                            w_cl=config.W_CL, grid_size=grid)          # un-weighted, trainer.py:483-489
+                            w_cl=config.W_CL, grid_size=grid,          # un-weighted, trainer.py:483-489
+                            three_term=getattr(config, "THREE_TERM_LOSS", False))
 
     feed = make_feed(test_loader, device, 0, 1)
     bg = config.NUM_CLASSES - 1

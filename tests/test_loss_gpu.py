@@ -108,3 +108,116 @@ def test_every_variant_at_ragged_sizes(gpu_device, n_cells):
             assert none is None and grad.shape == lg.shape
             assert abs(value.item() - ref) <= 1e-5 * ref, (dtype, labels.dtype, value.item(), ref)
             assert abs(value2.item() - ref) <= 1e-5 * ref, (dtype, labels.dtype, value2.item(), ref)
+
+
+# ---- the three-term loss of smrl_seld_gaussian.py:946-1072 (csrc/loss3.hip) ----------------------------------------
+
+def _three_term_reference(logits, dense, grid, w):
+    """The reference's own composition, restated with this package's loss.py (its AIUR / CL methods are pinned to the
+    reference's loss.py by tests/golden/loss_golden.npz: `aiur_on_probs`, `cl_on_probs`)."""
+    import loss as loss_mod
+    crit = loss_mod.SMRSELDLoss("mse", *w, grid_size=grid)
+    lg = logits.detach().float().clone().requires_grad_(True)
+    probs = torch.softmax(lg, -1)
+    mse = torch.nn.functional.mse_loss(probs, dense)
+    aiur = crit.aiur_loss(probs, dense)
+    cl = crit.converging_localization_loss(probs, dense)
+    total = w[0] * mse + w[1] * aiur + w[2] * cl
+    total.backward()
+    return torch.stack((total, mse, aiur, cl)).detach(), lg.grad
+
+
+def test_three_term_matches_reference_loss_golden(gpu_device, golden_dir):
+    import seld_native
+    z = np.load(golden_dir / "loss_golden.npz")
+    logits = torch.from_numpy(z["logits"]).to(gpu_device)
+    dense = torch.from_numpy(z["labels"]).to(gpu_device)
+    w = (1.0, 0.5, 0.25)
+    terms, grad = seld_native.smr_loss(logits, dense, (18, 36), *w, want_grad=True)
+    mse, aiur, cl = float(z["mse"]), float(z["aiur_on_probs"]), float(z["cl_on_probs"])      # the reference's numbers
+    got = terms.cpu().tolist()
+    assert abs(got[1] - mse) <= 1e-5 * mse and abs(got[2] - aiur) <= 1e-6 and abs(got[3] - cl) <= 1e-5 * abs(cl) + 1e-9
+    assert abs(got[0] - (w[0] * mse + w[1] * aiur + w[2] * cl)) <= 1e-6
+    ref_terms, ref_grad = _three_term_reference(logits, dense, (18, 36), w)
+    assert (grad - ref_grad).abs().max().item() <= 1e-4 * ref_grad.abs().max().item()
+    # the class-term part of the gradient is the reference's own (mse_grad), the rest is the CL term
+    only_mse, g_mse = seld_native.smr_loss(logits, dense, (18, 36), 1.0, 0.0, 0.0, want_grad=True)
+    assert np.abs(g_mse.cpu().numpy() - z["mse_grad"]).max() <= 1e-3 * np.abs(z["mse_grad"]).max()
+    # deterministic, and the compact mask gives the same numbers as the dense labels it encodes
+    again, grad2 = seld_native.smr_loss(logits, dense, (18, 36), *w, want_grad=True)
+    assert torch.equal(again, terms) and torch.equal(grad2, grad)
+    bits = (dense == 1.0).to(torch.int32) * (1 << torch.arange(14, device=gpu_device, dtype=torch.int32))
+    mask = bits.sum(-1)
+    mask = torch.where(mask == (1 << 13), torch.zeros_like(mask), mask).to(torch.uint16)       # background rule: mask 0
+    t3, g3 = seld_native.smr_loss(logits, mask, (18, 36), *w, want_grad=True)
+    assert torch.equal(t3, terms) and torch.equal(g3, grad)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("frames,grid", [(1, (18, 36)), (7, (18, 36)), (500, (18, 36)), (33, (5, 7)), (4, (3, 3))])
+def test_three_term_every_variant(gpu_device, dtype, frames, grid):
+    """fp32 / bf16 logits x mask / dense labels x value-only / value + gradient against torch, with frames that have no
+    event at all (IoU 1, no CL contribution), multi-hot cells, and grids small enough that a 256-cell tile spans many
+    frames (the per-frame event counts then go straight to global counters)."""
+    import seld_native
+    import loss as loss_mod
+    g = torch.Generator().manual_seed(frames * 100 + grid[0])
+    cells = grid[0] * grid[1]
+    logits = (torch.randn(frames, cells, 14, generator=g) * 2).to(gpu_device).to(dtype)
+    cls = torch.randint(0, 13, (frames, cells), generator=g).to(torch.int32)
+    mask = torch.where(torch.rand(frames, cells, generator=g) < 0.06, torch.ones(1, dtype=torch.int32) << cls,
+                       torch.zeros(1, dtype=torch.int32))
+    mask = mask | torch.where(torch.rand(frames, cells, generator=g) < 0.01, torch.full((1,), 1 << 5, dtype=torch.int32),
+                              torch.zeros(1, dtype=torch.int32))                 # a few second classes in a cell
+    mask[::3] = 0                                                               # every third frame has no events
+    mask = mask.to(torch.uint16).to(gpu_device)
+    dense = loss_mod.mask_to_dense(mask, 14)
+    w = (1.0, 0.7, 1.3)
+    ref_terms, ref_grad = _three_term_reference(logits, dense, grid, w)
+    for labels in (mask, dense):
+        terms, none = seld_native.smr_loss(logits, labels, grid, *w, want_grad=False)
+        terms2, grad = seld_native.smr_loss(logits, labels, grid, *w, want_grad=True)
+        assert none is None and torch.equal(terms, terms2) and grad.dtype == dtype
+        assert (terms - ref_terms).abs().max().item() <= 2e-5 * max(1.0, ref_terms.abs().max().item()), (terms, ref_terms)
+        tol = 1e-4 if dtype == torch.float32 else 8e-3
+        assert (grad.float() - ref_grad).abs().max().item() <= tol * ref_grad.abs().max().item()
+
+
+def test_three_term_module_and_config5_training_step(gpu_device):
+    """BASELINE configs[4] on one GPU: ResNet50-Conformer + Gaussian label augmentation + the three-term loss under bf16,
+    through the captured training step; the breakdown carries the reference's three keys."""
+    import dataset
+    import loss as loss_mod
+    import trainer
+    from oracle import features as ofeat
+    from oracle import labels as olab
+    cfg = trainer.config
+    saved = (cfg.MODEL_TYPE, cfg.SEED)
+    cfg.MODEL_TYPE, cfg.SEED = "resnet_conformer", 3
+    try:
+        clips = [ofeat.synth_pcm(i, 4, 24000 * 8, "noise") for i in range(2)]
+        rows = [olab.synth_metadata(i, meta_frames=80) for i in range(2)]
+        ds = dataset.SELDDataset.from_pcm(clips, rows, device=gpu_device, use_gaussian_augmentation=True)
+        plain = dataset.SELDDataset.from_pcm(clips, rows, device=gpu_device, use_gaussian_augmentation=False)
+        assert int((ds.mask_tm != 0).sum()) > 2 * int((plain.mask_tm != 0).sum())          # boxes, not single cells
+        torch.manual_seed(0)
+        model = trainer.prepare_model_for_device(trainer.build_model((ds.I, ds.J)), gpu_device).train()
+        trainer.enable_master_weights(model, gpu_device)
+        crit = loss_mod.SMRSELDLoss("mse", 1.0, 1.0, 1.0, grid_size=(ds.I, ds.J), three_term=True)
+        opt = trainer.make_optimizer(model, 1e-3, gpu_device, capturable=trainer.graph_step_enabled(gpu_device))
+        step = trainer.make_stepper(model, crit, opt, gpu_device)
+        spec, mask = ds.device_batch([0, 3])
+        losses = []
+        for _ in range(6):
+            total, term = step(spec, mask)
+            losses.append(total.item())
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+        t = crit.last_terms.cpu().tolist()
+        assert abs(t[0] - (t[1] + t[2] + t[3])) <= 1e-5 and 0 < t[1] < 1 and 0 <= t[2] <= 1
+        with torch.no_grad(), trainer.autocast_context(gpu_device):
+            total, breakdown = crit(model.eval()(spec), mask)
+        assert set(breakdown) == {"class_mse", "aiur", "cl"}
+        if hasattr(step, "close"):
+            step.close()
+    finally:
+        cfg.MODEL_TYPE, cfg.SEED = saved
