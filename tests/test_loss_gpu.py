@@ -163,14 +163,14 @@ def test_three_term_every_variant(gpu_device, dtype, frames, grid):
     import loss as loss_mod
     g = torch.Generator().manual_seed(frames * 100 + grid[0])
     cells = grid[0] * grid[1]
-    logits = (torch.randn(frames, cells, 14, generator=g) * 2).to(gpu_device).to(dtype)
+    logits = (torch.randn(1, frames, cells, 14, generator=g) * 2).to(gpu_device).to(dtype)        # [B, T, G, M]
     cls = torch.randint(0, 13, (frames, cells), generator=g).to(torch.int32)
     mask = torch.where(torch.rand(frames, cells, generator=g) < 0.06, torch.ones(1, dtype=torch.int32) << cls,
                        torch.zeros(1, dtype=torch.int32))
     mask = mask | torch.where(torch.rand(frames, cells, generator=g) < 0.01, torch.full((1,), 1 << 5, dtype=torch.int32),
                               torch.zeros(1, dtype=torch.int32))                 # a few second classes in a cell
     mask[::3] = 0                                                               # every third frame has no events
-    mask = mask.to(torch.uint16).to(gpu_device)
+    mask = mask.to(torch.uint16).to(gpu_device).unsqueeze(0)
     dense = loss_mod.mask_to_dense(mask, 14)
     w = (1.0, 0.7, 1.3)
     ref_terms, ref_grad = _three_term_reference(logits, dense, grid, w)
