@@ -56,7 +56,9 @@ __global__ __launch_bounds__(kMainWaves * 64, 2) void logmel_main_kernel(LogmelA
   // Zero the wavefront's tile once: pad cells are otherwise never written and the mel phase multiplies
   // over-read cells by a zero weight (0 * NaN would poison the sum).
   for (int i = lane; i < kLdsFloatsPerWave; i += 64) lds[i] = 0.0f;
-  const int b0 = a.tab.mel_b0[lane];
+  const int seg = a.tab.mel_pos[lane];
+  float* pp[16];
+  power_row_pointers(lane, lds, a.tab.mel_pos, pp);
   __syncthreads();
 
   const long total = a.rows * a.interior;
@@ -90,10 +92,10 @@ __global__ __launch_bounds__(kMainWaves * 64, 2) void logmel_main_kernel(LogmelA
     load_samples<T, true>(lane, pcm + nrow * a.L, a.L, nitr * kFramesPerIter + 2 * h, s);   // prefetch
     float mr[16], mi[16];
     phase_c_load(lane, lds, mr, mi);
-    phase_c_store(lane, lds, zr, zi, mr, mi);
+    phase_c_store(lane, pp, zr, zi, mr, mi);
     SELD_WAVE_SYNC();
     LaneAcc acc;
-    phase_d_accumulate(lane, lds, tab, b0, acc);
+    phase_d_accumulate(lane, lds, tab, seg, acc);
     SELD_WAVE_SYNC();
     float db[kFramesPerIter];
     phase_d_finish(lane, lds, acc, db);
@@ -118,7 +120,9 @@ __global__ __launch_bounds__(kEdgeWaves * 64, 1) void logmel_edge_kernel(LogmelA
   float* lds = smem + kTabFloats + wave * kLdsFloatsPerWave;
   fill_tables(a, tab, tid, kEdgeWaves * 64);
   for (int i = lane; i < kLdsFloatsPerWave; i += 64) lds[i] = 0.0f;
-  const int b0 = a.tab.mel_b0[lane];
+  const int seg = a.tab.mel_pos[lane];
+  float* pp[16];
+  power_row_pointers(lane, lds, a.tab.mel_pos, pp);
   __syncthreads();
 
   const long e = static_cast<long>(blockIdx.x) * kEdgeWaves + wave;
@@ -140,10 +144,10 @@ __global__ __launch_bounds__(kEdgeWaves * 64, 1) void logmel_edge_kernel(LogmelA
   SELD_WAVE_SYNC();
   float mr[16], mi[16];
   phase_c_load(lane, lds, mr, mi);
-  phase_c_store(lane, lds, zr, zi, mr, mi);
+  phase_c_store(lane, pp, zr, zi, mr, mi);
   SELD_WAVE_SYNC();
   LaneAcc acc;
-  phase_d_accumulate(lane, lds, tab, b0, acc);
+  phase_d_accumulate(lane, lds, tab, seg, acc);
   SELD_WAVE_SYNC();
   float db[kFramesPerIter];
   phase_d_finish(lane, lds, acc, db);

@@ -87,4 +87,35 @@ inline const char* build_sparse_mel(const std::vector<float>& fb, std::vector<in
   return nullptr;
 }
 
+// Placement of the power rows (logmel_core.h, kPPitch): pos[0..63] = seg[j], the start of lane j's segment, chosen
+// greedily in filter order as the first multiple of 4 floats behind the previous segment whose 16-byte bank group,
+// (seg / 4) mod 16, is still free in the lane's ds_read_b128 service group; pos[64 + 32 r + l] = where bin l + 32 r is
+// written (kPDummy for bins no filter uses and for l + 32 r > 480).  Error text if the rows do not fit.
+inline const char* place_power_rows(const std::vector<float>& fb, const std::vector<int>& b0, std::vector<int>& pos) {
+  std::vector<int> cnt(kMels, 0), owner(kBins, -1);
+  for (int k = 0; k < kBins; ++k)
+    for (int j = 0; j < kMels; ++j)
+      if (fb[static_cast<size_t>(k) * kMels + j] != 0.0f) {
+        owner[k] = j;
+        ++cnt[j];
+        break;
+      }
+  pos.assign(kMelPosInts, kPDummy);
+  bool used[4][16] = {};
+  int end = 0;
+  for (int j = 0; j < kMels; ++j) {
+    const int g = b128_lane_group(j);
+    int s = (end + 3) & ~3;
+    while (used[g][(s >> 2) & 15]) s += 4;
+    used[g][(s >> 2) & 15] = true;
+    pos[j] = s;
+    end = s + (cnt[j] > 0 ? cnt[j] : 1);
+    // a lane reads kMelMaxCnt cells from seg[j] on (zero weights past its own bins): they must exist and not be the dummy
+    if (s + kMelMaxCnt > kPDummy) return "mel filterbank: the power rows do not fit the LDS tile";
+  }
+  for (int k = 0; k < kBins; ++k)
+    if (owner[k] >= 0) pos[64 + k] = pos[owner[k]] + (k - b0[owner[k]]);
+  return nullptr;
+}
+
 }  // namespace seld

@@ -44,6 +44,10 @@ static int upload_mel(DeviceState& st, const std::vector<float>& fb) {
   std::vector<float> wd, wu;
   const char* why = build_sparse_mel(fb, b0, wd, wu);
   if (why) return fail(kErrUnsupported, why);
+  std::vector<int> pos;
+  why = place_power_rows(fb, b0, pos);
+  if (why) return fail(kErrUnsupported, why);
+  SELD_HIP_TRY(hipMemcpy(st.mel_pos, pos.data(), pos.size() * sizeof(int), hipMemcpyHostToDevice));
   SELD_HIP_TRY(hipMemcpy(st.mel_b0, b0.data(), b0.size() * sizeof(int), hipMemcpyHostToDevice));
   SELD_HIP_TRY(hipMemcpy(st.mel_wd, wd.data(), wd.size() * sizeof(float), hipMemcpyHostToDevice));
   SELD_HIP_TRY(hipMemcpy(st.mel_wu, wu.data(), wu.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -76,6 +80,7 @@ int seld_init(int device) {
   SELD_HIP_TRY(hipMalloc(&st.window, window.size() * sizeof(float)));
   SELD_HIP_TRY(hipMalloc(&st.twiddle, twiddle.size() * sizeof(float)));
   SELD_HIP_TRY(hipMalloc(&st.mel_b0, kMels * sizeof(int)));
+  SELD_HIP_TRY(hipMalloc(&st.mel_pos, kMelPosInts * sizeof(int)));
   SELD_HIP_TRY(hipMalloc(&st.mel_wd, kMels * kMelMaxCnt * sizeof(float)));
   SELD_HIP_TRY(hipMalloc(&st.mel_wu, kMels * kMelMaxCnt * sizeof(float)));
   SELD_HIP_TRY(hipMalloc(&st.mel_fb, static_cast<size_t>(kBins) * kMels * sizeof(float)));
@@ -102,6 +107,7 @@ int seld_shutdown(void) {
     (void)hipFree(st.window);
     (void)hipFree(st.twiddle);
     (void)hipFree(st.mel_b0);
+    (void)hipFree(st.mel_pos);
     (void)hipFree(st.mel_wd);
     (void)hipFree(st.mel_wu);
     (void)hipFree(st.mel_fb);

@@ -38,6 +38,7 @@ struct DeviceState {
   int* mel_b0 = nullptr;
   float* mel_wd = nullptr;
   float* mel_wu = nullptr;
+  int* mel_pos = nullptr;       // power-row placement (logmel_tables.h, place_power_rows)
   float* mel_fb = nullptr;      // dense [481][64] copy (used by the intensity-vector / debug paths)
   // side stream + fork/join events: the tiny edge kernel of the log-mel path overlaps the main kernel
   hipStream_t side_stream = nullptr;
@@ -45,7 +46,7 @@ struct DeviceState {
   // kernels that need more dynamic LDS than the default limit: hipFuncSetAttribute is per DEVICE (and is not a stream
   // operation: done once so that launches stay graph-capturable); one bit per kernel family, see need_lds()
   unsigned lds_attr_done = 0;
-  LogmelTables tables() const { return LogmelTables{window, twiddle, mel_b0, mel_wd, mel_wu}; }
+  LogmelTables tables() const { return LogmelTables{window, twiddle, mel_b0, mel_wd, mel_wu, mel_pos}; }
 };
 
 enum LdsAttrBit : unsigned {

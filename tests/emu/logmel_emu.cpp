@@ -19,8 +19,10 @@ namespace {
 
 struct HostTables {
   std::vector<float> window, twiddle, fb, wd, wu;
-  std::vector<int> b0;
-  LogmelTables view() const { return LogmelTables{window.data(), twiddle.data(), b0.data(), wd.data(), wu.data()}; }
+  std::vector<int> b0, pos;
+  LogmelTables view() const {
+    return LogmelTables{window.data(), twiddle.data(), b0.data(), wd.data(), wu.data(), pos.data()};
+  }
 };
 
 template <typename T>
@@ -34,6 +36,7 @@ int run(const T* pcm, int64_t N, int64_t C, int64_t L, float* out, int layout, c
   else
     default_mel_filterbank(t.fb);
   if (build_sparse_mel(t.fb, t.b0, t.wd, t.wu)) return -4;
+  if (place_power_rows(t.fb, t.b0, t.pos)) return -5;
   const LogmelTables tab = t.view();
 
   const long F = 1 + L / kHop;
@@ -72,13 +75,16 @@ int run(const T* pcm, int64_t N, int64_t C, int64_t L, float* out, int layout, c
       for (int lane = 0; lane < 64; ++lane)
         phase_c_load(lane, lds.data(), *reinterpret_cast<float(*)[16]>(&mr[lane * 16]),
                      *reinterpret_cast<float(*)[16]>(&mi[lane * 16]));
-      for (int lane = 0; lane < 64; ++lane)
-        phase_c_store(lane, lds.data(), *reinterpret_cast<float(*)[kN2]>(&zr[lane * kN2]),
+      for (int lane = 0; lane < 64; ++lane) {
+        float* pp[16];
+        power_row_pointers(lane, lds.data(), t.pos.data(), pp);
+        phase_c_store(lane, pp, *reinterpret_cast<float(*)[kN2]>(&zr[lane * kN2]),
                       *reinterpret_cast<float(*)[kN2]>(&zi[lane * kN2]),
                       *reinterpret_cast<float(*)[16]>(&mr[lane * 16]),
                       *reinterpret_cast<float(*)[16]>(&mi[lane * 16]));
+      }
       for (int lane = 0; lane < 64; ++lane)
-        phase_d_accumulate(lane, lds.data(), tab_lds.data(), t.b0[lane], acc[lane]);
+        phase_d_accumulate(lane, lds.data(), tab_lds.data(), t.pos[lane], acc[lane]);
       for (int lane = 0; lane < 64; ++lane) {
         float db[kFramesPerIter];
         phase_d_finish(lane, lds.data(), acc[lane], db);
