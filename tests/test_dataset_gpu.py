@@ -142,9 +142,38 @@ def _main_py_call_sequence(cfg, dataset, trainer, clips, tmp_path):
                     "visualizations", "checkpoint_epoch"):
             assert key in results
         assert results["num_frames_with_events"] > 0 and len(results["visualizations"]) == 2
+        _check_test_model_against_the_reference_metrics(cfg, trainer, test_ds, test_loader, results)
     cfg.DEVICE_FEED = True
     # both batch sources train the same model on the same windows (different shuffles / bf16 noise): same ballpark
     assert abs(losses[True][-1] - losses[False][-1]) <= 0.2 * max(losses[True][-1], losses[False][-1])
+
+
+def _check_test_model_against_the_reference_metrics(cfg, trainer, test_ds, test_loader, results):
+    """test_model's on-device reductions (argmax accuracies, event counts from the compact mask, frames with events)
+    against the reference's own formulas on dense host arrays (oracle/evalmetrics.py: trainer.py:542-556, 621-635):
+    same checkpoint, every test window through the stock DataLoader path, all predictions and labels collected."""
+    from oracle import evalmetrics
+    dev = torch.device("cuda")
+    ckpt = torch.load(cfg.CHECKPOINT_PATH / "best_model.pth", weights_only=False)          # written by this test run
+    model = trainer.prepare_model_for_device(trainer.build_model((test_ds.I, test_ds.J)), dev)
+    model.load_state_dict(ckpt["model_state_dict"])
+    model.eval()
+    preds, labels, losses = [], [], []
+    with torch.no_grad():
+        for spec, lab in test_loader:                        # CPU tensors, dense labels (dataset.py:319-330)
+            with trainer.autocast_context(dev):
+                out = model(spec.to(dev)).float()
+            losses.append(torch.nn.functional.mse_loss(torch.softmax(out, -1), lab.to(dev)).item())
+            preds.append(out.cpu().numpy())
+            labels.append(lab.numpy())
+    preds, labels = np.concatenate(preds), np.concatenate(labels)
+    overall, non_bg, active, cells = evalmetrics.accuracies(preds, labels, cfg.NUM_CLASSES)
+    assert abs(results["overall_accuracy"] - overall) <= 1e-3 and abs(results["non_bg_accuracy"] - non_bg) <= 1e-3
+    frames = evalmetrics.frames_with_events(labels, cfg.NUM_CLASSES)
+    assert results["num_frames_with_events"] == len(frames)
+    assert abs(results["test_loss"] - float(np.mean(losses))) <= 1e-4 * float(np.mean(losses))   # trainer.py:524-525
+    for viz in results["visualizations"]:
+        assert (viz["window_idx"], viz["time_idx"], viz["num_active"]) in set(frames)
 
 
 def test_mic_array_gcc_feature_set_end_to_end(gpu_device, tmp_path):
