@@ -52,6 +52,16 @@ class _Conv3x3(torch.autograd.Function):
                 dx = F.conv2d(dy, wt, padding=1)
                 if dx.dtype != x_dtype:
                     dx = dx.to(x_dtype)
+            import seld_overlap
+            if seld_overlap.conv_wgrad_side and seld_overlap.enabled:
+                # side stream, beside the rest of the data-gradient chain (seld_overlap.launch_now); the stepper joins
+                dw = torch.empty_like(wc, dtype=w_dtype)
+
+                def job():
+                    dw.copy_(torch.ops.aten.convolution_backward(dy, xc, wc, None, (1, 1), (1, 1), (1, 1), False, (0, 0),
+                                                                 1, (False, True, False))[1])
+                seld_overlap.launch_now(dy.device, [dy, xc, wc, dw], job)
+                return dx, dw
             dw = torch.ops.aten.convolution_backward(dy, xc, wc, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
                                                      (False, True, False))[1]
         return dx, dw if dw.dtype == w_dtype else dw.to(w_dtype)

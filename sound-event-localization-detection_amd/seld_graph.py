@@ -97,6 +97,8 @@ class GraphedTrainStep:
         self.device, self.world = device, world
         self.autocast = autocast if autocast is not None else nullcontext
         self.use_graphs = bool(use_graphs) and device.type == "cuda"
+        import os
+        self.wgrad_side = os.environ.get("SELD_WGRAD_SIDE", "1") != "0"     # developer switch for A/B runs
         self.params = [p for p in _unwrap(model).parameters() if p.requires_grad]
         self.flat = FlatGradients(self.params) if world > 1 else None
         self.shapes = {}             # key -> dict(calls, spec, labels, graph_a, graph_b, out)
@@ -118,7 +120,16 @@ class GraphedTrainStep:
         with self.autocast():
             predictions = self.model(spec)
         total, term = self.criterion.loss_tensor(predictions, labels)
-        total.backward()
+        side = self.wgrad_side and self.device.type == "cuda"
+        if side:
+            import seld_overlap
+            seld_overlap.conv_wgrad_side = True
+        try:
+            total.backward()
+        finally:
+            if side:
+                seld_overlap.conv_wgrad_side = False
+                seld_overlap.join(self.device)           # weight gradients produced on the side stream are complete
         if self.flat is not None:
             self.flat.gather()
         return total.detach(), term.detach()

@@ -89,6 +89,9 @@ class _BiGRULayer(torch.autograd.Function):
             if ctx.overlap:
                 # on the side stream, beside the recurrence of the layer below (seld_overlap.launch_pending there)
                 seld_overlap.submit(dy.device, [dgi, dghn, y, xc, dw_ih, dw_hh], weight_grads)
+            elif seld_overlap.conv_wgrad_side and seld_overlap.enabled and dy.is_cuda:
+                # layer 0 under the captured step: beside the convolution backward (joined by the stepper)
+                seld_overlap.launch_now(dy.device, [dgi, dghn, y, xc, dw_ih, dw_hh], weight_grads)
             else:
                 weight_grads()
             db_ih, db_hh = seld_native.gru_bias_grads(dbias)                       # [6H], [6H] fp32, one launch

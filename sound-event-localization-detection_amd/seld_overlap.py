@@ -72,6 +72,34 @@ def launch_pending(device):
     return len(jobs)
 
 
+# ---- convolution weight gradients beside the data-gradient chain --------------------------------------------------------
+# Below GRU layer 0 the backward pass is the chain  tail(k) -> dgrad(k) -> tail(k-1) -> ...  with the weight gradient
+# of block k hanging off tail(k): nothing needs it before the optimiser.  The tails are HBM-bound, the convolutions
+# MFMA-bound, so a weight-gradient convolution on the side stream runs beside the next tail instead of after it.  Only the
+# captured training step turns this on (``conv_wgrad_side``): it joins the side stream itself right after backward();
+# under DistributedDataParallel the reducer's hooks read gradients when autograd delivers them, so the eager path keeps
+# everything on one stream.
+conv_wgrad_side = False
+
+
+def launch_now(device, tensors, job):
+    """Run ``job()`` on the side stream behind what the main stream holds now; ``join`` must follow before the results
+    are read on the main stream."""
+    main = torch.cuda.current_stream(device)
+    side = side_stream(device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        job()
+    for t in tensors:
+        t.record_stream(side)
+
+
+def join(device):
+    """The main stream waits for everything queued on the side stream (pending jobs are launched first)."""
+    launch_pending(device)
+    torch.cuda.current_stream(device).wait_stream(side_stream(device))
+
+
 class _Deferred(torch.autograd.Function):
     @staticmethod
     def forward(ctx, *params):
