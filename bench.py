@@ -217,6 +217,9 @@ class HotPath:
             spec = nat.gather_windows(spec_tm, starts, WINDOW, out=bufs[0] if bufs else None)
             mask = nat.gather_windows(self.mask_tm, starts, WINDOW, out=bufs[1] if bufs else None)
             last, _ = self.stepper(spec, mask)
+            if os.environ.get("SELD_BENCH_TRACE"):          # developer diagnostic (synchronises: never a measurement)
+                bad = [n for n, p in self.model.named_parameters() if not torch.isfinite(p).all()]
+                self.loss_trace = getattr(self, "loss_trace", []) + [(round(float(last.item()), 5), len(bad), bad[:4])]
         if timed:
             m1.record()
             self.model_events.append((m0, m1))
@@ -433,6 +436,17 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         in_sync = bool((hi - lo).abs().item() <= 1e-9 * max(1.0, abs(hi.item())))
+        out_of_sync = []
+        if not in_sync:          # name the tensors that differ (a diagnostic: this never happens in a healthy run)
+            with torch.no_grad():
+                each = torch.stack([p.double().sum() for p in hot.model.parameters()]).cpu()
+            both = [torch.zeros_like(each) for _ in range(world)]
+            dist.all_gather(both, each)
+            names = [n for n, _ in hot.model.named_parameters()]
+            for i, name in enumerate(names):
+                vals = [b[i].item() for b in both]
+                if any(v != vals[0] for v in vals) or any(v != v for v in vals):         # different, or NaN
+                    out_of_sync.append(f"{name} {vals}")
     if rank == 0:
         feat_ms = float(np.mean([a.elapsed_time(b) for a, b in hot.feat_events]))
         model_ms = float(np.mean([a.elapsed_time(b) for a, b in hot.model_events]))
@@ -475,10 +489,14 @@ def main():
         if world > 1:
             line["config"]["backend"] = "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend
             line["config"]["replicas_in_sync"] = in_sync
+            if out_of_sync:
+                line["config"]["replicas_out_of_sync"] = out_of_sync
             line["config"]["per_rank_clips_per_s"] = [CLIPS_PER_STEP * args.steps / t for t in per_rank]
             if backend != "nccl":
                 line["rehearsal"] = True          # ranks share a GPU over gloo: a functional check, not a measurement
         line["config"]["captured_step"] = hot.stepper.stats() if hasattr(hot.stepper, "stats") else None
+        if getattr(hot, "loss_trace", None):
+            line["config"]["loss_trace"] = hot.loss_trace
         if hasattr(hot.optimizer, "fused_casts"):
             line["config"]["master_weights"] = {"one_launch_gradient_casts": hot.optimizer.fused_casts,
                                                 "per_tensor_fallbacks": hot.optimizer.fallback_casts}

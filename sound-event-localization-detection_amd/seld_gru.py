@@ -29,10 +29,17 @@ def applicable(module, x):
 
 class _BiGRULayer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_ih, b_ih, w_hh, b_hh, overlap=False):
+    def forward(ctx, x, w_ih, b_ih, w_hh, b_hh, overlap=False, feature_cf=None):
         """x [B,T,In]; w_ih [6H,In]; b_ih [6H]; w_hh [2,3H,H]; b_hh [2,3H].  ``overlap``: the parameters are
-        ``seld_overlap.defer`` aliases -- their weight gradients may be produced on the side stream."""
+        ``seld_overlap.defer`` aliases -- their weight gradients may be produced on the side stream.
+        ``feature_cf = (C, F)``: x's features are ordered (frequency, channel) while w_ih's columns are (channel,
+        frequency): the columns are permuted here, and dW_ih is un-permuted by the SAME job that computes it -- so that
+        no kernel of the main stream reads a weight gradient the side stream may still be writing."""
         ctx.overlap = overlap
+        ctx.feature_cf = feature_cf
+        if feature_cf is not None:
+            c, f = feature_cf
+            w_ih = w_ih.view(w_ih.shape[0], c, f).transpose(1, 2).reshape(w_ih.shape[0], f * c)
         low = torch.is_autocast_enabled() or x.dtype == torch.bfloat16
         cdt = torch.bfloat16 if low else torch.float32
         with torch.autocast(device_type="cuda", enabled=False):
@@ -73,7 +80,12 @@ class _BiGRULayer(torch.autograd.Function):
             dw_hh = torch.empty((2, 3 * h, h), dtype=t_whh, device=dy.device)
 
             def weight_grads():
-                tall_product(dgi2, x2, out=dw_ih)                                # [6H, In]
+                if ctx.feature_cf is None:
+                    tall_product(dgi2, x2, out=dw_ih)                            # [6H, In]
+                else:                                                            # columns back to (channel, frequency)
+                    c, f = ctx.feature_cf
+                    perm = tall_product(dgi2, x2, out_dtype=t_wih)
+                    dw_ih.view(6 * h, c, f).copy_(perm.view(6 * h, f, c).transpose(1, 2))
                 # h_{t-1} of the forward recurrence: y shifted by one step in each direction's own time order
                 hp = seld_native.gru_previous_state(y).view(n, 2 * h)
                 # d/d(gh) = (da_r, da_z, da_n * r).  Two well-shaped products instead of eight skinny ones: all of
@@ -97,7 +109,7 @@ class _BiGRULayer(torch.autograd.Function):
             db_ih, db_hh = seld_native.gru_bias_grads(dbias)                       # [6H], [6H] fp32, one launch
             db_hh = db_hh.view(2, 3 * h)
         return dx.to(dy.dtype) if dx.dtype != dy.dtype and not torch.is_autocast_enabled() else dx, \
-            dw_ih, db_ih.to(t_bih), dw_hh, db_hh.to(t_bhh), None
+            dw_ih, db_ih.to(t_bih), dw_hh, db_hh.to(t_bhh), None, None
 
 
 class _Joined(torch.autograd.Function):
@@ -162,11 +174,8 @@ def bigru_forward(module, x, feature_cf=None, overlap=False, need_hn=True):
     finals = []
     for layer in range(module.num_layers):
         w_ih, b_ih, w_hh, b_hh = params[layer]
-        if layer == 0 and feature_cf is not None:
-            c, f = feature_cf
-            w_ih = w_ih.view(w_ih.shape[0], c, f).transpose(1, 2).reshape(w_ih.shape[0], f * c)
         out = _BiGRULayer.apply(out, w_ih, b_ih, w_hh.view(2, 3 * HIDDEN, HIDDEN), b_hh.view(2, 3 * HIDDEN),
-                                overlap and layer > 0)
+                                overlap and layer > 0, feature_cf if layer == 0 else None)
         if need_hn:
             finals += [out[:, -1, :HIDDEN], out[:, 0, HIDDEN:]]
         if module.training and module.dropout > 0 and layer + 1 < module.num_layers:
