@@ -117,7 +117,12 @@ class SELD_ResNet50_Conformer(nn.Module):
         y = x.permute(0, 2, 1, 3)
         if y.is_cuda:
             y = y.contiguous(memory_format=torch.channels_last)
-        y = self.encoder(y)                                          # [B, 2048, T, F/32]
+        if y.is_cuda:
+            import seld_convtail
+            with seld_convtail.batched_counters():                   # one launch for the 53 BatchNorm counters
+                y = self.encoder(y)                                  # [B, 2048, T, F/32]
+        else:
+            y = self.encoder(y)
         y = y.permute(0, 2, 1, 3).reshape(batch, frames, -1)
         y = self.dropout(self.proj(y))
         for block in self.conformer_blocks:

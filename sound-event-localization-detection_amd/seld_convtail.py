@@ -55,10 +55,34 @@ class _ConvTail(torch.autograd.Function):
         return dx, dres, dweight, dbias, None, None, None, None, None, None
 
 
+_collected = None          # the num_batches_tracked buffers of the fused tails run inside a ``batched_counters`` block
+
+
+class batched_counters:
+    """``with batched_counters():`` around an encoder's forward pass: the ``num_batches_tracked += 1`` of every fused
+    BatchNorm tail inside becomes ONE multi-tensor add at exit (4 launches per CRNN iteration, 53 per ResNet-50 one,
+    ~5 us apiece on a GPU-bound step); same values, nothing reads the counters in between (momentum is a constant)."""
+
+    def __enter__(self):
+        global _collected
+        self.outer, _collected = _collected, []
+        return self
+
+    def __exit__(self, *exc):
+        global _collected
+        mine, _collected = _collected, self.outer
+        if mine and exc[0] is None:
+            torch._foreach_add_(mine, 1)
+        return False
+
+
 def bn_relu(bn, x, pool=1, residual=None):
     """relu(bn(x)) [-> MaxPool2d((1, 2)) when pool = 2]; with ``residual``: relu(bn(x) + residual)."""
     if bn.training:
-        bn.num_batches_tracked.add_(1)
+        if _collected is not None:
+            _collected.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
     if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
         residual = residual.contiguous(memory_format=torch.channels_last)
     return _ConvTail.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
