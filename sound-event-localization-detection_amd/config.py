@@ -113,6 +113,9 @@ class Config:
     FEATURE_SET = "logmel"      # 'logmel' (the reference) | 'logmel_iv' (FOA: + 3 intensity-vector channels) |
                                 # 'logmel_gcc' (MIC array: + C(C-1)/2 GCC-PHAT channels); the model's n_channels
                                 # follows the dataset (4 -> 7, 8 -> 36)
+    FEATURE_CACHE_DIR = None    # directory for the per-recording COMPACT features (fp32 log-mel [T,C,64] + uint16 label mask
+                                # [T,648], 2.3 KB per frame): a later SELDDataset construction uploads them instead of
+                                # decoding and transforming the recording again
     THREE_TERM_LOSS = False     # total = W_CLASS * class + W_AIUR * AIUR + W_CL * CL on probabilities, as
                                 # smrl_seld_gaussian.py:1058-1072 (BASELINE configs[4]: with GAUSSIAN_AUGMENT and the
                                 # ResNet50-Conformer); False = the modular loss.py, class term only (loss.py:158-166)

@@ -237,9 +237,38 @@ class SELDDataset(Dataset):
         logger.info(f"SELDDataset initialized with {len(self)} windows")
 
     # -- construction -------------------------------------------------------------------------
+    def _cache_path(self, audio_path, metadata_path):
+        """Where this recording's compact features live under Config.FEATURE_CACHE_DIR, or None (cache off; Gaussian
+        label augmentation draws fresh noise per construction, smrl_seld_gaussian.py:397-534, so it is never cached).
+        The name carries everything the arrays depend on: both files' size and mtime, the feature set, the grid."""
+        root = getattr(config, "FEATURE_CACHE_DIR", None)
+        if not root or self.use_gaussian_augmentation:
+            return None
+        import hashlib
+        a, m = Path(audio_path), Path(metadata_path)
+        sa, sm = a.stat(), m.stat()
+        key = "|".join(str(v) for v in (a.resolve(), sa.st_size, sa.st_mtime_ns, m.resolve(), sm.st_size, sm.st_mtime_ns,
+                                        getattr(config, "FEATURE_SET", "logmel"), self.I, self.J, self.sample_rate, "v1"))
+        return Path(root) / f"{a.stem}.{hashlib.sha1(key.encode()).hexdigest()[:16]}.npz"
+
     def _file_features(self, audio_path, metadata_path):
         """One recording -> (spec_tm [T, C, 64] f32, mask [T, 648] u16) on the device, cropped to the
-        common frame count (dataset.py:224-249)."""
+        common frame count (dataset.py:224-249).  With Config.FEATURE_CACHE_DIR the pair is kept on disk in its COMPACT
+        form (1 KB of features + 1.3 KB of label mask per frame; the reference's dense tensors are 37 KB per frame) and a
+        later construction uploads it instead of decoding and transforming the recording again."""
+        cached = self._cache_path(audio_path, metadata_path)
+        if cached is not None and cached.exists():
+            with np.load(cached) as z:
+                return torch.from_numpy(z["spec"]).to(self.device), torch.from_numpy(z["mask"]).to(self.device)
+        spec, mask = self._file_features_uncached(audio_path, metadata_path)
+        if cached is not None:
+            cached.parent.mkdir(parents=True, exist_ok=True)
+            tmp = cached.with_suffix(".tmp.npz")
+            np.savez(tmp, spec=spec.cpu().numpy(), mask=mask.cpu().numpy())
+            tmp.replace(cached)                                # atomic: a concurrent rank sees nothing or the whole file
+        return spec, mask
+
+    def _file_features_uncached(self, audio_path, metadata_path):
         data, rate, bits = _read_wav(audio_path)
         if data.shape[0] != 4 and getattr(config, "FEATURE_SET", "logmel") != "logmel_gcc":
             logger.warning(f"Expected 4 channels but got {data.shape[0]} channels in {audio_path}")

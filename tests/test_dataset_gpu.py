@@ -223,3 +223,36 @@ def test_mic_array_gcc_feature_set_end_to_end(gpu_device, tmp_path):
         type(cfg).FEATURE_SET = "logmel"
         (cfg.FEATURE_SET, cfg.MODEL_TYPE, cfg.CRNN_CNN_CHANNELS, cfg.CRNN_RNN_HIDDEN, cfg.NUM_EPOCHS, cfg.BATCH_SIZE,
          cfg.OUTPUT_PATH, cfg.CHECKPOINT_PATH) = saved
+
+
+def test_feature_cache_round_trip(gpu_device, clips, tmp_path, monkeypatch):
+    """Config.FEATURE_CACHE_DIR: the second construction uploads the compact per-recording
+    arrays instead of running the feature / label kernels, and the dataset is bit-identical; a changed recording
+    invalidates its entry; Gaussian label augmentation (fresh noise per construction) is never cached."""
+    import dataset
+    import seld_native
+    cfg = dataset.config
+    items = [clips["fold3_room21_mix001"], clips["fold3_room21_mix002"]]
+    wavs, csvs = [c["wav"] for c in items], [c["csv"] for c in items]
+    plain = dataset.SELDDataset(wavs, csvs)
+    monkeypatch.setattr(cfg, "FEATURE_CACHE_DIR", str(tmp_path / "cache"), raising=False)
+    first = dataset.SELDDataset(wavs, csvs)
+    files = sorted((tmp_path / "cache").glob("*.npz"))
+    assert len(files) == 2 and all(f.stat().st_size < 2.6e3 * plain.total_frames for f in files)   # compact: ~2.3 KB / frame
+    calls = []
+    real = seld_native.spatial_features
+    monkeypatch.setattr(seld_native, "spatial_features", lambda *a, **k: calls.append(1) or real(*a, **k))
+    second = dataset.SELDDataset(wavs, csvs)
+    assert not calls                                                      # nothing was recomputed
+    for ds in (first, second):
+        assert torch.equal(ds.spec_tm, plain.spec_tm) and torch.equal(ds.mask_tm, plain.mask_tm)
+        assert np.array_equal(ds.window_starts, plain.window_starts)
+    # a recording that changed on disk gets a new entry
+    import os
+    st = os.stat(wavs[0])
+    os.utime(wavs[0], ns=(st.st_atime_ns, st.st_mtime_ns + 1_000_000_000))
+    dataset.SELDDataset(wavs[:1], csvs[:1])
+    assert calls and len(list((tmp_path / "cache").glob("*.npz"))) == 3
+    del calls[:]
+    dataset.SELDDataset(wavs[:1], csvs[:1], use_gaussian_augmentation=True)
+    assert calls and len(list((tmp_path / "cache").glob("*.npz"))) == 3
