@@ -34,6 +34,9 @@ if timed.exists():                      # the timed region only (MIOpen find-mod
     shutil.copy(timed, out / f"{tag}_bench_timed_region_stats.csv")
     if (src_prof / "timed_region.log").exists():
         shutil.copy(src_prof / "timed_region.log", out / f"{tag}_bench_timed_region.txt")
+timeline = src_prof / "iteration_timeline.txt"
+if timeline.exists():                   # every dispatch of one optimiser iteration (tools/iter_timeline.py)
+    (out / f"{tag}_iteration_timeline.txt").write_text("".join(l[:170].rstrip() + "\n" for l in open(timeline)))
 if src_pmc.exists():
     for p in sorted(src_pmc.glob("pass*.csv")):
         shutil.copy(p, out / f"{tag}_pmc_logmel_{p.name}")
