@@ -93,8 +93,9 @@ class Config:
     FUSED_CONV_TAIL = True      # BatchNorm -> ReLU -> MaxPool of the CNN blocks in two HBM passes (csrc/convtail.hip)
     CONV_DGRAD_AS_FORWARD = True  # encoder 3x3 convs: data gradient as a forward conv with transposed, flipped weights
     FUSED_DWCONV = "auto"       # channels-last Conformer conv module with the HIP depthwise Conv1d (csrc/dwconv.hip):
-                                # fewer GPU microseconds but more host work; "auto" = modules with d_model >= 512 (measured
-                                # +3 % on the ResNet50-Conformer, -7 % on the host-bound d_model-256 Conformer)
+                                # fewer GPU microseconds but more host work; "auto" = always under GRAPH_STEP (no host work
+                                # per iteration), else modules with d_model >= 512 (eager: +3 % on the ResNet50-Conformer,
+                                # -7 % on the host-bound d_model-256 Conformer)
     FUSED_LAYERNORM = True      # head: LayerNorm -> ReLU in one kernel, activations stay bf16 (csrc/layernorm.hip)
     OVERLAP_WEIGHT_GRADS = True  # CRNN: weight gradients of the head and of GRU layer 1 on a side HIP stream, under the
                                 # backward recurrences that occupy 16 of the 256 CUs (seld_overlap.py)

@@ -11,7 +11,7 @@ model_conformer.py:58-62.
 import torch
 import torch.nn as nn
 
-from seld_layernorm import run_head
+from seld_layernorm import norm as layer_norm_of, run_head
 from seld_linear import SeldLinear
 import torch.nn.functional as F
 
@@ -35,7 +35,7 @@ class FeedForward(nn.Module):
         self.swish = Swish()
 
     def forward(self, x):
-        y = self.dropout(self.swish(self.linear1(self.norm(x))))
+        y = self.dropout(self.swish(self.linear1(layer_norm_of(self.norm, x))))
         return x + 0.5 * self.dropout(self.linear2(y))
 
 
@@ -61,7 +61,7 @@ class MultiHeadSelfAttention(nn.Module):
 
     def forward(self, x):
         b, t, d = x.shape
-        y = self.norm(x)
+        y = layer_norm_of(self.norm, x)
         q, k, v = self._heads(self.w_q, y), self._heads(self.w_k, y), self._heads(self.w_v, y)
         ctx = F.scaled_dot_product_attention(q, k, v, dropout_p=self.dropout.p if self.training else 0.0)
         ctx = ctx.transpose(1, 2).reshape(b, t, d)
@@ -88,7 +88,7 @@ class ConformerConvModule(nn.Module):
             import seld_dwconv
             if seld_dwconv.applicable(self, x):                       # channels-last evaluation (csrc/dwconv.hip)
                 return seld_dwconv.conv_module_forward(self, x)
-        y = self.layer_norm(x).transpose(1, 2)                       # [B, D, T]
+        y = layer_norm_of(self.layer_norm, x).transpose(1, 2)        # [B, D, T]
         y = self.glu(self.pointwise_conv1(y))
         y = self.swish(self.batch_norm(self.depthwise_conv(y)))
         y = self.dropout(self.pointwise_conv2(y))
@@ -105,7 +105,7 @@ class ConformerBlock(nn.Module):
         self.norm = nn.LayerNorm(d_model)
 
     def forward(self, x):
-        return self.norm(self.ff2(self.conv(self.attn(self.ff1(x)))))
+        return layer_norm_of(self.norm, self.ff2(self.conv(self.attn(self.ff1(x)))))
 
 
 class SELD_Conformer(nn.Module):

@@ -53,7 +53,8 @@ def applicable(module, x):
 def conv_module_forward(module, x):
     """ConformerConvModule.forward on [B, T, D] without leaving that layout."""
     b, t, d = x.shape
-    y = module.layer_norm(x)
+    import seld_layernorm
+    y = seld_layernorm.norm(module.layer_norm, x)
     p1, p2, dw = module.pointwise_conv1, module.pointwise_conv2, module.depthwise_conv
     y = _Linear.apply(y, p1.weight.squeeze(-1), p1.bias)                    # [B, T, 2D]
     y = F.glu(y, dim=-1)

@@ -43,6 +43,16 @@ def layer_norm(ln, x, relu=False):
     return _LayerNorm.apply(x, ln.weight, ln.bias, ln.eps, relu)
 
 
+def norm(ln, x):
+    """``ln(x)`` for the LayerNorms inside the Conformer blocks (model_conformer.py:10-29,31-69,71-113): the fused kernel
+    keeps the activation's dtype -- under bf16 autocast the stock module casts to fp32, normalises and the next Linear
+    casts back (two framework copies around every one of the 10 / 20 LayerNorms of a Conformer / ResNet50-Conformer
+    iteration) -- statistics and arithmetic in fp32 either way."""
+    if x.is_cuda and applicable(ln, x):
+        return layer_norm(ln, x, relu=False)
+    return ln(x)
+
+
 def run_head(head, x):
     """``head(x)`` for the  Linear, LayerNorm, ReLU, Dropout, Linear  Sequential of the three models."""
     if (len(head) == 5 and isinstance(head[1], nn.LayerNorm) and isinstance(head[2], nn.ReLU)

@@ -95,6 +95,10 @@ def prepare_model_for_device(model, device):
         if os.environ.get("SELD_DWCONV") is None:
             import seld_dwconv
             seld_dwconv.enabled = getattr(config, "FUSED_DWCONV", "auto")
+            # "auto" weighed fewer GPU microseconds against more host work (round 1: +3 % at d_model 512, -7 % on the
+            # host-bound d_model-256 Conformer); a captured iteration has no host work to weigh
+            if seld_dwconv.enabled == "auto" and graph_step_enabled(device):
+                seld_dwconv.enabled = True
         import seld_layernorm
         seld_layernorm.enabled = bool(getattr(config, "FUSED_LAYERNORM", True)) and \
             os.environ.get("SELD_LAYERNORM", "1") != "0"            # developer switch for A/B runs
