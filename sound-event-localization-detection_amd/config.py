@@ -107,6 +107,8 @@ class Config:
     GRAPH_STEP = True           # one optimiser iteration = one replayed HIP graph per input shape (seld_graph.py): the eager
                                 # loop spends ~3.5 ms of host time enqueueing ~300 launches per CRNN iteration; data
                                 # parallel: graph (forward + backward) -> flat all-reduce -> graph (Adam)
+    TUNED_GEMMS = True          # apply tuned/gemm_gfx950.csv: hipBLASLt / rocBLAS kernel selections for the models' GEMM
+                                # shapes, timed offline on an MI355X (seld_tuned.py; ignored on any other library stack)
     DDP_BUCKET_MB = 8           # RCCL all-reduce bucket size: with bf16 working weights the CRNN's gradients are 22 MB, so
                                 # 8 MB gives three buckets -- the head's (ready first) reduces under the GRU / conv backward
     SYNC_BATCHNORM = False      # per-rank BN statistics by default

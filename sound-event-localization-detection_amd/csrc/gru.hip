@@ -200,7 +200,7 @@ struct GruFwdArgs {
 // The MFMA computes gh^T = W_hh h^T: M = gate rows (units), N = sequence columns; D[m = 4q+i][n = c].  The step
 // body has NO divergent control flow (batch padded to whole tiles by the host; kSave compile time): the compiler
 // counts outstanding loads / stores exactly and never drains the queue.
-template <typename T, bool kSave>
+template <typename T, bool kSave, int kOrder>
 __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* wn_lds, __hip_bfloat16* hbuf,
                                                   const bf16x8 (&wr)[2][8], const bf16x8 (&wz)[2][8]) {
   typedef typename Types<T>::Data D;
@@ -263,36 +263,88 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
       for (int i = 0; i < 4; ++i) acc_r[s][i] = acc_z[s][i] = acc_n[s][i] = 0.0f;
     const __hip_bfloat16* hrow = hbuf + (cur * kSeqs + seq) * kHPitch + 8 * q;
     const bf16x8* wnp = wn_lds + wave * 2 * 8 * 64 + lane;
-    bf16x8 hfrag = *reinterpret_cast<const bf16x8*>(hrow);
-    bf16x8 wn0 = wnp[0], wn1 = wnp[8 * 64];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      bf16x8 hfrag_n = hfrag, wn0_n = wn0, wn1_n = wn1;
-      if (kk + 1 < 8) {
-        hfrag_n = *reinterpret_cast<const bf16x8*>(hrow + 32 * (kk + 1));
-        wn0_n = wnp[(kk + 1) * 64];
-        wn1_n = wnp[(8 + kk + 1) * 64];
-      }
-      acc_r[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[0][kk], hfrag, acc_r[0], 0, 0, 0);
-      acc_z[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wz[0][kk], hfrag, acc_z[0], 0, 0, 0);
-      acc_n[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn0, hfrag, acc_n[0], 0, 0, 0);
-      acc_r[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[1][kk], hfrag, acc_r[1], 0, 0, 0);
-      acc_z[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wz[1][kk], hfrag, acc_z[1], 0, 0, 0);
-      acc_n[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn1, hfrag, acc_n[1], 0, 0, 0);
-      hfrag = hfrag_n;
-      wn0 = wn0_n;
-      wn1 = wn1_n;
-    }
-    // ---- gates for this lane's (sequence, kU units)
     float ghr[kU], ghz[kU], gg[kU], rr[kU], zz[kU], nn[kU], hh[kU];
-    own_values(acc_r, ghr);
-    own_values(acc_z, ghz);
-    own_values(acc_n, gg);
+    if (kOrder == 0) {
+      bf16x8 hfrag = *reinterpret_cast<const bf16x8*>(hrow);
+      bf16x8 wn0 = wnp[0], wn1 = wnp[8 * 64];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        bf16x8 hfrag_n = hfrag, wn0_n = wn0, wn1_n = wn1;
+        if (kk + 1 < 8) {
+          hfrag_n = *reinterpret_cast<const bf16x8*>(hrow + 32 * (kk + 1));
+          wn0_n = wnp[(kk + 1) * 64];
+          wn1_n = wnp[(8 + kk + 1) * 64];
+        }
+        acc_r[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[0][kk], hfrag, acc_r[0], 0, 0, 0);
+        acc_z[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wz[0][kk], hfrag, acc_z[0], 0, 0, 0);
+        acc_n[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn0, hfrag, acc_n[0], 0, 0, 0);
+        acc_r[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[1][kk], hfrag, acc_r[1], 0, 0, 0);
+        acc_z[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wz[1][kk], hfrag, acc_z[1], 0, 0, 0);
+        acc_n[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn1, hfrag, acc_n[1], 0, 0, 0);
+        hfrag = hfrag_n;
+        wn0 = wn0_n;
+        wn1 = wn1_n;
+      }
+      // ---- gates for this lane's (sequence, kU units)
+      own_values(acc_r, ghr);
+      own_values(acc_z, ghz);
+      own_values(acc_n, gg);
+#pragma unroll
+      for (int i = 0; i < kU; ++i) {
+        gg[i] += bias_n[i];
+        rr[i] = sigmoid_f(gir[i] + ghr[i]);
+        zz[i] = sigmoid_f(giz[i] + ghz[i]);
+      }
+    } else {
+      // ---- gate-major: all of r, then z, then n.  A 16x16x32 MFMA holds the SIMD's vector issue for 8 of its 16
+      // cycles: the redistribution + sigmoid of a finished gate issues in the gaps of the next gate's MFMAs (this
+      // wavefront's and the co-resident one's) instead of after all 48; only the n gate's tanh and the state
+      // update remain behind the last MFMA.  The 8 B fragments of h are read once and kept (32 VGPRs).
+      // The B fragments of h are re-read from LDS for every gate (16 B per lane and k-step, one k-step ahead: keeping
+      // all 8 would cost 32 registers the kernel does not have).
+      auto hread = [&](int kk) { return *reinterpret_cast<const bf16x8*>(hrow + 32 * (kk & 7)); };
+      bf16x8 hfrag = hread(0);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const bf16x8 hnext = hread(kk + 1);
+        acc_r[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[0][kk], hfrag, acc_r[0], 0, 0, 0);
+        acc_r[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[1][kk], hfrag, acc_r[1], 0, 0, 0);
+        hfrag = hnext;
+      }
+      own_values(acc_r, ghr);
+#pragma unroll
+      for (int i = 0; i < kU; ++i) rr[i] = sigmoid_f(gir[i] + ghr[i]);
+      bf16x8 wn0 = wnp[0], wn1 = wnp[8 * 64];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const bf16x8 hnext = hread(kk + 1);
+        acc_z[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wz[0][kk], hfrag, acc_z[0], 0, 0, 0);
+        acc_z[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wz[1][kk], hfrag, acc_z[1], 0, 0, 0);
+        hfrag = hnext;
+      }
+      own_values(acc_z, ghz);
+#pragma unroll
+      for (int i = 0; i < kU; ++i) zz[i] = sigmoid_f(giz[i] + ghz[i]);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        bf16x8 hnext = hfrag, wn0_n = wn0, wn1_n = wn1;
+        if (kk + 1 < 8) {
+          hnext = hread(kk + 1);
+          wn0_n = wnp[(kk + 1) * 64];
+          wn1_n = wnp[(8 + kk + 1) * 64];
+        }
+        acc_n[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn0, hfrag, acc_n[0], 0, 0, 0);
+        acc_n[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn1, hfrag, acc_n[1], 0, 0, 0);
+        hfrag = hnext;
+        wn0 = wn0_n;
+        wn1 = wn1_n;
+      }
+      own_values(acc_n, gg);
+#pragma unroll
+      for (int i = 0; i < kU; ++i) gg[i] += bias_n[i];
+    }
 #pragma unroll
     for (int i = 0; i < kU; ++i) {
-      gg[i] += bias_n[i];
-      rr[i] = sigmoid_f(gir[i] + ghr[i]);
-      zz[i] = sigmoid_f(giz[i] + ghz[i]);
       nn[i] = tanh_f(fmaf(rr[i], gg[i], gin[i]));
       hh[i] = fmaf(zz[i], h_prev[i] - nn[i], nn[i]);
       h_prev[i] = hh[i];
@@ -331,7 +383,7 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
   if (t < a.T) step(t, g_b);
 }
 
-template <typename T>
+template <typename T, int kOrder>
 __global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16x8* wn_lds = reinterpret_cast<bf16x8*>(smem);
@@ -360,8 +412,8 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs 
 #endif
   for (int i = tid; i < 2 * kSeqs * kHPitch; i += kGruThreads) hbuf[i] = __float2bfloat16(0.0f);   // h_0 = 0
   __syncthreads();
-  if (a.saved) gru_forward_steps<T, true>(a, wn_lds, hbuf, wr, wz);
-  else gru_forward_steps<T, false>(a, wn_lds, hbuf, wr, wz);
+  if (a.saved) gru_forward_steps<T, true, kOrder>(a, wn_lds, hbuf, wr, wz);
+  else gru_forward_steps<T, false, kOrder>(a, wn_lds, hbuf, wr, wz);
 }
 
 // ---- 4-wavefront variant: ALL of W_hh in registers ------------------------------------------------------------------
@@ -877,9 +929,11 @@ int seld_gru_forward(const void* gi, int is_bf16, const void* w_hh_bf16, const f
   const size_t lds = kWnBytes + 2 * kSeqs * kHPitch * sizeof(__hip_bfloat16);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (need_lds(st, kAttrGruForward)) {     // once per device (seld_common.h)
-    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_forward_kernel<__hip_bfloat16>),
+    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_forward_kernel<__hip_bfloat16, 0>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_forward_kernel<float>),
+    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_forward_kernel<__hip_bfloat16, 1>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_forward_kernel<float, 0>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     lds_attr_set(st, kAttrGruForward);
   }
@@ -889,13 +943,17 @@ int seld_gru_forward(const void* gi, int is_bf16, const void* w_hh_bf16, const f
   // wavefronts of the 8-wavefront kernel overlap each other's phases, which is worth more than the LDS weight reads cost.
   static const int variant = [] {
     const char* v = getenv("SELD_GRU_FORWARD");
-    return v && v[0] == '4' ? 4 : 8;
+    return v && v[0] == '4' ? 4 : v && v[0] == 'g' ? 1 : 8;      // 'g': gate-major MFMA order (bf16)
   }();
   if (variant == 4 && is_bf16) {          // (the fp32 instantiation of the 4-wavefront kernel spills: 8 wavefronts there)
     hipLaunchKernelGGL(gru_forward4_kernel<__hip_bfloat16>, grid, dim3(kGru4Threads), 0, stream, a);
   } else {
-    if (is_bf16) hipLaunchKernelGGL(gru_forward_kernel<__hip_bfloat16>, grid, dim3(kGruThreads), lds, stream, a);
-    else hipLaunchKernelGGL(gru_forward_kernel<float>, grid, dim3(kGruThreads), lds, stream, a);
+    if (is_bf16 && variant == 1)
+      hipLaunchKernelGGL((gru_forward_kernel<__hip_bfloat16, 1>), grid, dim3(kGruThreads), lds, stream, a);
+    else if (is_bf16)
+      hipLaunchKernelGGL((gru_forward_kernel<__hip_bfloat16, 0>), grid, dim3(kGruThreads), lds, stream, a);
+    else
+      hipLaunchKernelGGL((gru_forward_kernel<float, 0>), grid, dim3(kGruThreads), lds, stream, a);
   }
   SELD_HIP_TRY(hipGetLastError());
   return kOk;

@@ -108,6 +108,8 @@ def prepare_model_for_device(model, device):
         for module in model.modules():
             if isinstance(module, SeldGRU) and SeldGRU.fused_enabled:
                 seld_gru.pack_parameters(module)
+        import seld_tuned
+        seld_tuned.enable(device, bool(getattr(config, "TUNED_GEMMS", True)))
     SMRSELDLoss.fused_enabled = bool(getattr(config, "FUSED_LOSS", True))
     return model
 

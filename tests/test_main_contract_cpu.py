@@ -60,3 +60,18 @@ def test_config_attributes_and_result_keys(contract, tmp_path):
     for key in contract["dict_keys"]["test_results"]:
         needle = 'f"class_{config.LOSS_TYPE}"' if key == "class_{}" else f'"{key}"'
         assert needle in src_test, key
+
+
+def test_tuned_gemm_table_is_well_formed_and_inert_on_the_cpu():
+    """seld_tuned.py: the shipped table carries the library versions it was tuned with and only GEMM rows; on a CPU
+    device nothing is switched on."""
+    import torch
+    import seld_tuned
+    rows = [line.split(",") for line in seld_tuned.TABLE.read_text().splitlines() if line]
+    validators = {r[1] for r in rows if r[0] == "Validator"}
+    assert {"PT_VERSION", "HIPBLASLT_VERSION", "ROCBLAS_VERSION", "GCN_ARCH_NAME"} <= validators
+    assert any(r[1] == "GCN_ARCH_NAME" and r[2].startswith("gfx950") for r in rows)
+    entries = [r for r in rows if r[0] != "Validator"]
+    assert entries and all(r[0].startswith("Gemm") and len(r) == 4 for r in entries)
+    before = dict(seld_tuned.state)
+    assert seld_tuned.enable(torch.device("cpu")) == before
