@@ -61,8 +61,12 @@ __global__ __launch_bounds__(kMainWaves * 64, 2) void logmel_main_kernel(LogmelA
   power_row_pointers(lane, lds, a.tab.mel_pos, pp);
   __syncthreads();
 
+  // Which iterations this wavefront runs is the same for its 64 lanes: with the wavefront index read through
+  // readfirstlane the whole bookkeeping (row, iteration, clip / channel of the row, the division that starts it) lives in
+  // scalar registers and the scalar unit; derived from threadIdx it was ~120 vector instructions of 64-bit division per
+  // iteration (out_pointer's row / C).
   const long total = a.rows * a.interior;
-  const long gw = static_cast<long>(blockIdx.x) * kMainWaves + wave;
+  const long gw = static_cast<long>(blockIdx.x) * kMainWaves + __builtin_amdgcn_readfirstlane(wave);
   const long begin = gw * a.chunk;
   const long end = begin + a.chunk < total ? begin + a.chunk : total;
   if (begin >= end) return;
@@ -70,29 +74,35 @@ __global__ __launch_bounds__(kMainWaves * 64, 2) void logmel_main_kernel(LogmelA
 
   long row = begin / a.interior;
   long itr = 1 + (begin - row * a.interior);
+  long clip = row / a.C;
+  long chan = row - clip * a.C;
+  float* const out_lane = a.out + lane * a.sM;
   float s[48];
   load_samples<T, true>(lane, pcm + row * a.L, a.L, itr * kFramesPerIter + 2 * h, s);
 
 #pragma unroll 1
   for (long it = begin; it < end; ++it) {
-    long nrow = row, nitr = itr;
+    long nrow = row, nitr = itr, nclip = clip, nchan = chan;
     if (it + 1 < end) {                       // scalar bookkeeping only; the fetch below is unconditional
       ++nitr;
-      if (nitr > a.interior) { nitr = 1; ++nrow; }
+      if (nitr > a.interior) {
+        nitr = 1;
+        ++nrow;
+        if (++nchan == a.C) { nchan = 0; ++nclip; }
+      }
     }
-    float* outp = out_pointer(a, row, itr, lane);
-
+    float* outp = out_lane + (clip * a.sN + chan * a.sC + itr * kFramesPerIter * a.sT);
     phase_a(lane, s, tab, lds);
     SELD_WAVE_SYNC();
-    float zr[kN2], zi[kN2];
-    phase_b(lane, lds, zr, zi);
+    cf z[kN2];
+    phase_b(lane, lds, z);
     SELD_WAVE_SYNC();
-    phase_b_store(lane, lds, zr, zi);
+    phase_b_store(lane, lds, z);
     SELD_WAVE_SYNC();
     load_samples<T, true>(lane, pcm + nrow * a.L, a.L, nitr * kFramesPerIter + 2 * h, s);   // prefetch
-    float mr[16], mi[16];
-    phase_c_load(lane, lds, mr, mi);
-    phase_c_store(lane, pp, zr, zi, mr, mi);
+    cf m[16];
+    phase_c_load(lane, lds, m);
+    phase_c_store(lane, pp, z, m);
     SELD_WAVE_SYNC();
     LaneAcc acc;
     phase_d_accumulate(lane, lds, tab, seg, acc);
@@ -104,6 +114,8 @@ __global__ __launch_bounds__(kMainWaves * 64, 2) void logmel_main_kernel(LogmelA
     SELD_WAVE_SYNC();
     row = nrow;
     itr = nitr;
+    clip = nclip;
+    chan = nchan;
   }
 }
 
@@ -137,14 +149,14 @@ __global__ __launch_bounds__(kEdgeWaves * 64, 1) void logmel_edge_kernel(LogmelA
   load_samples<T, false>(lane, pcm + row * a.L, a.L, tf + 2 * h, s);
   phase_a(lane, s, tab, lds);
   SELD_WAVE_SYNC();
-  float zr[kN2], zi[kN2];
-  phase_b(lane, lds, zr, zi);
+  cf z[kN2];
+  phase_b(lane, lds, z);
   SELD_WAVE_SYNC();
-  phase_b_store(lane, lds, zr, zi);
+  phase_b_store(lane, lds, z);
   SELD_WAVE_SYNC();
-  float mr[16], mi[16];
-  phase_c_load(lane, lds, mr, mi);
-  phase_c_store(lane, pp, zr, zi, mr, mi);
+  cf m[16];
+  phase_c_load(lane, lds, m);
+  phase_c_store(lane, pp, z, m);
   SELD_WAVE_SYNC();
   LaneAcc acc;
   phase_d_accumulate(lane, lds, tab, seg, acc);
@@ -190,16 +202,16 @@ __global__ __launch_bounds__(kEdgeWaves * 64, 2) void stft_kernel(LogmelArgs a) 
     else load_samples<T, false>(lane, pcm + row * a.L, a.L, tf + 2 * h, s);
     phase_a(lane, s, tab, lds);
     SELD_WAVE_SYNC();
-    float zr[kN2], zi[kN2];
-    phase_b(lane, lds, zr, zi);
+    cf z[kN2];
+    phase_b(lane, lds, z);
     SELD_WAVE_SYNC();
-    phase_b_store(lane, lds, zr, zi);
+    phase_b_store(lane, lds, z);
     SELD_WAVE_SYNC();
-    float mr[16], mi[16];
-    phase_c_load(lane, lds, mr, mi);
+    cf m[16];
+    phase_c_load(lane, lds, m);
     const long fa = tf + 2 * h;
     float* base = a.out + (row * a.F + fa) * (2 * kBins);
-    phase_c_spectrum(lane, zr, zi, mr, mi, fa < a.F ? base : nullptr, fa + 1 < a.F ? base + 2 * kBins : nullptr);
+    phase_c_spectrum(lane, z, m, fa < a.F ? base : nullptr, fa + 1 < a.F ? base + 2 * kBins : nullptr);
     SELD_WAVE_SYNC();
   }
 }

@@ -87,9 +87,9 @@ SELD_HD int b128_lane_group(int lane) {
   return (first ? 0 : 1) + 2 * (lane >> 5);
 }
 
+// per frame slot: (A_j, B_j) -- the sums over this lane's bins weighted for its own filter and for the next one
 struct LaneAcc {
-  float a[kFramesPerIter];
-  float b[kFramesPerIter];
+  cf ab[kFramesPerIter];
 };
 
 SELD_HD int e_index(int h, int k1, int n2) { return ((h * kN1 + k1) * kEPitch + n2) * 2; }
@@ -145,35 +145,25 @@ SELD_HD void load_samples(int lane, const T* row, long L, long fa, float (&s)[48
 
 // Tail of stage A: multiply the 32-pt DFT outputs by the two-level twiddles W_960^{n2*k1} = hi[k1>>3]*lo[k1&7]
 // (`tw_lane` = this lane's quad in the twiddle table rows: [5][64][4] floats, row v at +256 v) and store
-// column l of this half-wavefront's [32][31]-complex exchange tile.
-SELD_HD void stage_a_finish(int lane, const float (&re)[kN1], const float (&im)[kN1], const float* tw_lane, float* lds) {
+// column l of this half-wavefront's [32][31]-complex exchange tile (one 8-byte store per element).
+SELD_HD void stage_a_finish(int lane, const cf (&z)[kN1], const float* tw_lane, float* lds) {
   const int h = lane >> 5;
   const int l = lane & 31;
-  float tw[20];
+  cf tw[10];
 #pragma unroll
-  for (int v = 0; v < 5; ++v)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) tw[4 * v + j] = tw_lane[v * 256 + j];
+  for (int v = 0; v < 5; ++v) {
+    tw[2 * v] = cf_make(tw_lane[v * 256], tw_lane[v * 256 + 1]);
+    tw[2 * v + 1] = cf_make(tw_lane[v * 256 + 2], tw_lane[v * 256 + 3]);
+  }
   if (l < kN2) {
     float* e = lds + e_index(h, 0, l);                 // column l of this half's tile; row k1 is at +62*k1
 #pragma unroll
     for (int k1 = 0; k1 < kN1; ++k1) {
       const int a = k1 >> 3, b = k1 & 7;
-      float yr = re[k1], yi = im[k1];
-      if (b != 0) {
-        const float cr = tw[2 * (b - 1)], ci = tw[2 * (b - 1) + 1];
-        const float tr = yr * cr - yi * ci;
-        yi = yr * ci + yi * cr;
-        yr = tr;
-      }
-      if (a != 0) {
-        const float cr = tw[2 * (6 + a)], ci = tw[2 * (6 + a) + 1];
-        const float tr = yr * cr - yi * ci;
-        yi = yr * ci + yi * cr;
-        yr = tr;
-      }
-      e[k1 * kEPitch * 2] = yr;
-      e[k1 * kEPitch * 2 + 1] = yi;
+      cf y = z[k1];
+      if (b != 0) y = cf_cmul(y, tw[b - 1]);
+      if (a != 0) y = cf_cmul(y, tw[6 + a]);
+      *reinterpret_cast<cf*>(e + k1 * kEPitch * 2) = y;
     }
   }
 }
@@ -188,64 +178,50 @@ SELD_HD void phase_a(int lane, const float (&s)[48], const float* tab, float* ld
   const int h = lane >> 5;
   const int l = lane & 31;
   const float* tl = tab + lane * 4;                    // this lane's quad in every table row
-  float re[kN1], im[kN1];
+  cf z[kN1];
 #pragma unroll
   for (int qd = 0; qd < 8; ++qd) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n1 = 4 * qd + j;
       const float w = tl[kTabWin + qd * 256 + j];        // 0.5 * Hann (see table_value)
-      re[n1] = w * s[n1];            // frame fa
-      im[n1] = w * s[n1 + 16];       // frame fa+1 = same samples shifted by 480 = 16*30
+      // frame fa -> real part, frame fa+1 (the same samples shifted by 480 = 16*30) -> imaginary part
+      z[n1] = cf_make(w * s[n1], w * s[n1 + 16]);
     }
   }
-  dft32(re, im);
-  stage_a_finish(lane, re, im, tl + kTabTw, lds);
+  dft32(z);
+  stage_a_finish(lane, z, tl + kTabTw, lds);
 }
 
 // ---- Phase B: 30-pt DFT along n2 for row k1 = l, then park the upper half-spectrum for the mirror read.
-SELD_HD void phase_b(int lane, float* lds, float (&zr)[kN2], float (&zi)[kN2]) {
+SELD_HD void phase_b(int lane, float* lds, cf (&z)[kN2]) {
   const int h = lane >> 5;
   const int l = lane & 31;
-  const float* e = lds + e_index(h, l, 0);             // row l
+  const cf* e = reinterpret_cast<const cf*>(lds + e_index(h, l, 0));   // row l
 #pragma unroll
-  for (int n2 = 0; n2 < kN2; ++n2) {
-    zr[n2] = e[2 * n2];
-    zi[n2] = e[2 * n2 + 1];
-  }
-  dft30(zr, zi);   // zr/zi[k2] = Z[l + 32*k2]
+  for (int n2 = 0; n2 < kN2; ++n2) z[n2] = e[n2];
+  dft30(z);   // z[k2] = Z[l + 32*k2]
 }
 
-SELD_HD void phase_b_store(int lane, float* lds, const float (&zr)[kN2], const float (&zi)[kN2]) {
+SELD_HD void phase_b_store(int lane, float* lds, const cf (&z)[kN2]) {
   const int h = lane >> 5;
   const int l = lane & 31;
-  float* z = lds + zm_index(h, l);                     // entry (l + 32*k2 - 480) is at +64*(k2-15)
+  cf* zm = reinterpret_cast<cf*>(lds + zm_index(h, l));  // entry (l + 32*k2 - 480) is at +32*(k2-15) complex
 #pragma unroll
-  for (int k2 = 15; k2 < kN2; ++k2) {
-    z[64 * (k2 - 15)] = zr[k2];
-    z[64 * (k2 - 15) + 1] = zi[k2];
-  }
-  if (l == 0) {   // Z[960] == Z[0]
-    z[960] = zr[0];
-    z[961] = zi[0];
-  }
+  for (int k2 = 15; k2 < kN2; ++k2) zm[32 * (k2 - 15)] = z[k2];
+  if (l == 0) zm[480] = z[0];   // Z[960] == Z[0]
 }
 
 // ---- Phase C: un-pack the two real spectra and write |X|^2 for bins 0..480 of both frames.
 //   Xa[k] = (Z[k] + conj Z[N-k]) / 2 ,  Xb[k] = (Z[k] - conj Z[N-k]) / (2i); the 1/2 is in the window table
-SELD_HD void phase_c_load(int lane, const float* lds, float (&mr)[16], float (&mi)[16]) {
+SELD_HD void phase_c_load(int lane, const float* lds, cf (&m)[16]) {
   const int h = lane >> 5;
   const int l = lane & 31;
-  // mirror entry 480 - (l + 32 r) = (0 - l) + 32*(15 - r): base at r = 15 (entry -l), ascending by 64 floats
-  const float* m = lds + zm_index(h, 0) - 2 * l;
+  // mirror entry 480 - (l + 32 r) = (0 - l) + 32*(15 - r): base at r = 15 (entry -l), ascending by 32 complex
+  const cf* mp = reinterpret_cast<const cf*>(lds + zm_index(h, 0) - 2 * l);
 #pragma unroll
-  for (int r = 0; r < 15; ++r) {
-    mr[r] = m[64 * (15 - r)];
-    mi[r] = m[64 * (15 - r) + 1];
-  }
-  const float* m0 = lds + zm_index(h, 0);              // r = 15: bin 480 (lane 0 only; others read a dummy)
-  mr[15] = m0[0];
-  mi[15] = m0[1];
+  for (int r = 0; r < 15; ++r) m[r] = mp[32 * (15 - r)];
+  m[15] = *reinterpret_cast<const cf*>(lds + zm_index(h, 0));   // r = 15: bin 480 (lane 0 only; others read a dummy)
 }
 
 // Where this lane's 16 bins (l + 32 r) live in the power row of frame slot 2h (slot 2h+1 is kPPitch further): loop
@@ -257,39 +233,35 @@ SELD_HD void power_row_pointers(int lane, float* lds, const int* mel_pos, float*
   for (int r = 0; r < 16; ++r) pp[r] = lds + kPOff + 2 * h * kPPitch + mel_pos[64 + 32 * r + l];
 }
 
-SELD_HD void phase_c_store(int lane, float* const (&pp)[16], const float (&zr)[kN2], const float (&zi)[kN2],
-                           const float (&mr)[16], const float (&mi)[16]) {
+// With Z = (zr, zi) and the mirror M = (mr, mi):  Xa = (zr + mr, zi - mi),  Xb = (zi + mi, -(zr - mr)).  The two powers
+// come out as ONE pair in four packed operations:  U = (zr + mr, zr - mr),  V = (zi - mi, zi + mi),
+// (|Xa|^2, |Xb|^2) = U * U + V * V  (splats of zr, mr, zi, mi are operand selects).
+SELD_HD void phase_c_store(int lane, float* const (&pp)[16], const cf (&z)[kN2], const cf (&m)[16]) {
   const int l = lane & 31;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     if (r < 15 || l == 0) {
-      const float ar = zr[r] + mr[r], ai = zi[r] - mi[r];
-      const float br = zi[r] + mi[r], bi = zr[r] - mr[r];
-      pp[r][0] = ar * ar + ai * ai;
-      pp[r][kPPitch] = br * br + bi * bi;
+      const cf u = cf_fma(cf_make(m[r].x, m[r].x), cf_make(1.0f, -1.0f), cf_make(z[r].x, z[r].x));
+      const cf v = cf_fma(cf_make(m[r].y, m[r].y), cf_make(-1.0f, 1.0f), cf_make(z[r].y, z[r].y));
+      const cf p = cf_fma(v, v, cf_mul(u, u));
+      pp[r][0] = p.x;
+      pp[r][kPPitch] = p.y;
     }
   }
 }
 
 // Variant of phase C for the STFT export: the un-packed complex spectra of the two frames go straight to
 // global memory (frame-major rows of 481 complex: 32 lanes x 8 B = one 256-B run per store).
-//   Xa = (ar, ai) ,  Xb = (br, -bi)   with the quantities of phase_c_store (the 1/2 is in the window table)
-SELD_HD void phase_c_spectrum(int lane, const float (&zr)[kN2], const float (&zi)[kN2], const float (&mr)[16],
-                              const float (&mi)[16], float* row_a, float* row_b) {
+//   Xa = (zr + mr, zi - mi) ,  Xb = (zi + mi, mr - zr)   (the 1/2 is in the window table)
+SELD_HD void phase_c_spectrum(int lane, const cf (&z)[kN2], const cf (&m)[16], float* row_a, float* row_b) {
   const int l = lane & 31;
-  float* pa = row_a ? row_a + 2 * l : nullptr;        // complex bin l + 32 r is at +64 r floats
-  float* pb = row_b ? row_b + 2 * l : nullptr;
+  cf* pa = row_a ? reinterpret_cast<cf*>(row_a) + l : nullptr;        // complex bin l + 32 r is at +32 r
+  cf* pb = row_b ? reinterpret_cast<cf*>(row_b) + l : nullptr;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     if (r < 15 || l == 0) {
-      if (pa) {
-        pa[64 * r] = zr[r] + mr[r];
-        pa[64 * r + 1] = zi[r] - mi[r];
-      }
-      if (pb) {
-        pb[64 * r] = zi[r] + mi[r];
-        pb[64 * r + 1] = mr[r] - zr[r];
-      }
+      if (pa) pa[32 * r] = cf_fma(m[r], cf_make(1.0f, -1.0f), z[r]);
+      if (pb) pb[32 * r] = cf_fma_swap(z[r], 1.0f, -1.0f, cf_make(m[r].y, m[r].x));
     }
   }
 }
@@ -301,25 +273,23 @@ SELD_HD void phase_d_accumulate(int lane, float* lds, const float* tab, int seg,
   // this lane's segment of the power rows; seg and kPPitch are multiples of 4 floats, the tile is 16-byte aligned
   const PowerQuad* p = reinterpret_cast<const PowerQuad*>(lds + kPOff + seg);
 #pragma unroll
-  for (int s = 0; s < kFramesPerIter; ++s) acc.a[s] = acc.b[s] = 0.0f;
+  for (int s = 0; s < kFramesPerIter; ++s) acc.ab[s] = cf_make(0.0f, 0.0f);
 #pragma unroll
   for (int iq = 0; iq < kMelMaxCnt / 4; ++iq) {
-    float w[8];                    // (wd, wu) of bins 4 iq .. 4 iq + 3 of this lane's segment
+    cf w[4];                       // (wd, wu) of bins 4 iq .. 4 iq + 3 of this lane's segment: pairs as the table stores them
 #pragma unroll
-    for (int k = 0; k < 8; ++k) w[k] = tl[(2 * iq + (k >> 2)) * 256 + (k & 3)];
+    for (int k = 0; k < 4; ++k) w[k] = cf_make(tl[(2 * iq + (k >> 1)) * 256 + 2 * (k & 1)], tl[(2 * iq + (k >> 1)) * 256 + 2 * (k & 1) + 1]);
 #pragma unroll
     for (int s = 0; s < kFramesPerIter; ++s) {
       const PowerQuad q = p[s * (kPPitch / 4) + iq];           // one ds_read_b128, conflict free (see kPPitch)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {                            // bins in ascending order: the sums of the dword version
-        acc.a[s] = fmaf(w[2 * k], q.p[k], acc.a[s]);
-        acc.b[s] = fmaf(w[2 * k + 1], q.p[k], acc.b[s]);
-      }
+      for (int k = 0; k < 4; ++k)                              // bins in ascending order; both sums in one packed fma
+        acc.ab[s] = cf_fma(w[k], cf_make(q.p[k], q.p[k]), acc.ab[s]);
     }
   }
   float* bs = lds + kBsOff + lane;
 #pragma unroll
-  for (int s = 0; s < kFramesPerIter; ++s) bs[s * 64] = acc.b[s];
+  for (int s = 0; s < kFramesPerIter; ++s) bs[s * 64] = acc.ab[s].y;
 }
 
 // 10*log10(max(p, 1e-10)) as 10*log10(2) * log2(p): one v_log_f32 (<= 1 ulp of log2, i.e. < 1e-5 dB) instead
@@ -337,7 +307,7 @@ SELD_HD void phase_d_finish(int lane, const float* lds, const LaneAcc& acc, floa
 #pragma unroll
   for (int s = 0; s < kFramesPerIter; ++s) {
     const float below = lane > 0 ? (lds + kBsOff + lane - 1)[s * 64] : 0.0f;
-    db[s] = power_to_db(acc.a[s] + below);
+    db[s] = power_to_db(acc.ab[s].x + below);
   }
 }
 

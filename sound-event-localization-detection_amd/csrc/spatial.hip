@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kGccWaves * 64, 2) void gcc_phat_kernel(GccArgs a) 
       const float2* xmb = sp2 + mb * kBins;
       const float2* xnb = sp2 + nb * kBins;
       // ---- stage A input: u[k] = conj(Ra[k] + i Rb[k]) at k = 30 n1 + n2 (Hermitian extension above bin 480)
-      float re[kN1], im[kN1];
+      cf z[kN1];
 #pragma unroll
       for (int n1 = 0; n1 < kN1; ++n1) {
         const int k = kN2 * n1 + n2;
@@ -192,11 +192,10 @@ __global__ __launch_bounds__(kGccWaves * 64, 2) void gcc_phat_kernel(GccArgs a) 
         phat(xma[kk], xna[kk], ar, ai);
         phat(xmb[kk], xnb[kk], br, bi);
         // k <= 480: Zhat = (ar - bi) + i (ai + br);  k > 480: Zhat = (ar + bi) + i (br - ai);  u = conj(Zhat)
-        re[n1] = upper ? ar + bi : ar - bi;
-        im[n1] = upper ? ai - br : -(ai + br);
+        z[n1] = cf_make(upper ? ar + bi : ar - bi, upper ? ai - br : -(ai + br));
       }
-      dft32(re, im);
-      stage_a_finish(lane, re, im, tw + lane * 4, lds);
+      dft32(z);
+      stage_a_finish(lane, z, tw + lane * 4, lds);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       // ---- stage B pruned to k2 = 0 and k2 = 29: S0 = sum_n2 E ,  S29 = sum_n2 E conj(W_30^{n2})

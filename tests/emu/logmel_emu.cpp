@@ -47,7 +47,7 @@ int run(const T* pcm, int64_t N, int64_t C, int64_t L, float* out, int layout, c
   std::vector<float> lds(kLdsFloatsPerWave, 0.0f);
   std::vector<float> tab_lds(kTabFloats);
   for (int e = 0; e < kTabFloats; ++e) tab_lds[e] = table_value(tab, e);
-  std::vector<float> zr(64 * kN2), zi(64 * kN2), mr(64 * 16), mi(64 * 16);
+  std::vector<cf> z(64 * kN2), m(64 * 16);
   std::vector<float> smp(64 * 48);
   std::vector<LaneAcc> acc(64);
   const long iters_per_row = (F + kFramesPerIter - 1) / kFramesPerIter;
@@ -67,21 +67,15 @@ int run(const T* pcm, int64_t N, int64_t C, int64_t L, float* out, int layout, c
       for (int lane = 0; lane < 64; ++lane)
         phase_a(lane, *reinterpret_cast<float(*)[48]>(&smp[lane * 48]), tab_lds.data(), lds.data());
       for (int lane = 0; lane < 64; ++lane)
-        phase_b(lane, lds.data(), *reinterpret_cast<float(*)[kN2]>(&zr[lane * kN2]),
-                *reinterpret_cast<float(*)[kN2]>(&zi[lane * kN2]));
+        phase_b(lane, lds.data(), *reinterpret_cast<cf(*)[kN2]>(&z[lane * kN2]));
       for (int lane = 0; lane < 64; ++lane)
-        phase_b_store(lane, lds.data(), *reinterpret_cast<float(*)[kN2]>(&zr[lane * kN2]),
-                      *reinterpret_cast<float(*)[kN2]>(&zi[lane * kN2]));
+        phase_b_store(lane, lds.data(), *reinterpret_cast<cf(*)[kN2]>(&z[lane * kN2]));
       for (int lane = 0; lane < 64; ++lane)
-        phase_c_load(lane, lds.data(), *reinterpret_cast<float(*)[16]>(&mr[lane * 16]),
-                     *reinterpret_cast<float(*)[16]>(&mi[lane * 16]));
+        phase_c_load(lane, lds.data(), *reinterpret_cast<cf(*)[16]>(&m[lane * 16]));
       for (int lane = 0; lane < 64; ++lane) {
         float* pp[16];
         power_row_pointers(lane, lds.data(), t.pos.data(), pp);
-        phase_c_store(lane, pp, *reinterpret_cast<float(*)[kN2]>(&zr[lane * kN2]),
-                      *reinterpret_cast<float(*)[kN2]>(&zi[lane * kN2]),
-                      *reinterpret_cast<float(*)[16]>(&mr[lane * 16]),
-                      *reinterpret_cast<float(*)[16]>(&mi[lane * 16]));
+        phase_c_store(lane, pp, *reinterpret_cast<cf(*)[kN2]>(&z[lane * kN2]), *reinterpret_cast<cf(*)[16]>(&m[lane * 16]));
       }
       for (int lane = 0; lane < 64; ++lane)
         phase_d_accumulate(lane, lds.data(), tab_lds.data(), t.pos[lane], acc[lane]);

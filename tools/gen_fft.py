@@ -7,10 +7,17 @@ This script emits both as fully unrolled ``__host__ __device__`` C++ (static ind
 so every element stays in a VGPR -- no scratch) into
 ``sound-event-localization-detection_amd/csrc/fft_gen.h``.
 
-  * 32 = 2^5        : radix-2 decimation-in-time recursion, trivial twiddles (1, -i, 45 deg)
-                      special-cased, the rest folded in as literal constants.
+  * 32 = 2^5        : radix-2 decimation-in-time recursion.
   * 30 = 2 x 3 x 5  : Good-Thomas prime-factor mapping (no twiddles at all) over hand
                       written 2/3/5-point butterflies.
+
+Every value is a COMPLEX number held as one (re, im) register pair (``cf``, seld_complex.h) and every emitted operation is
+one packed-fp32 instruction on gfx950 (``v_pk_add_f32`` / ``v_pk_mul_f32`` / ``v_pk_fma_f32``: two flops per lane and
+issue slot).  Round 1 emitted scalar code over separate re[] / im[] arrays and left the pairing to the compiler's SLP
+vectoriser: it found the packed instructions (494 of them in the two DFT stages) but had to assemble and take apart
+the register pairs around them with 338 ``v_mov_b32`` -- 40 % of the stage's issue slots.  Multiplications by
++-i and -1 cost nothing: they are carried as a pending rotation of the value and folded into the consumer
+(a + (-i) b  =  fma(swap(b), (1, -1), a): the swap is the instruction's op_sel modifier, the signs a constant pair).
 
 Forward transform, e^{-2 pi i nk/N}.  Output in natural order.
 Run:  python tools/gen_fft.py   (idempotent; the header is committed)
@@ -23,67 +30,89 @@ from pathlib import Path
 
 OUT = Path(__file__).resolve().parent.parent / "sound-event-localization-detection_amd" / "csrc" / "fft_gen.h"
 
+ROT = {0: 1 + 0j, 1: -1j, 2: -1 + 0j, 3: 1j}     # pending rotation index r: value = (-i)^r * name
+
 
 def lit(v: float) -> str:
-    return repr(float(v)) + "f" if "e" in repr(float(v)) or "." in repr(float(v)) else repr(float(v)) + ".0f"
+    r = repr(float(v))
+    return r + "f"
 
 
 class Emitter:
-    """Three-address straight-line code; a complex value is a pair of C expressions."""
+    """Three-address straight-line code over complex values (name, rot): the value is (-i)^rot * name."""
 
     def __init__(self):
         self.lines = []
         self.count = 0
-        self.flops = 0
+        self.ops = 0
 
-    def new(self, expr: str, flops: int = 1) -> str:
+    def new(self, expr: str, ops: int = 1) -> str:
         name = f"t{self.count}"
         self.count += 1
-        self.flops += flops
-        self.lines.append(f"  const float {name} = {expr};")
+        self.ops += ops
+        self.lines.append(f"  const cf {name} = {expr};")
         return name
 
-    # -- complex helpers -------------------------------------------------------------
+    # a + (-i)^k b  as one packed instruction
+    def _add_rot(self, na, nb, k):
+        k %= 4
+        if k == 0:
+            return self.new(f"cf_add({na}, {nb})")
+        if k == 2:
+            return self.new(f"cf_sub({na}, {nb})")
+        if k == 1:      # a - i b = (a.x + b.y, a.y - b.x)
+            return self.new(f"cf_fma_swap({nb}, 1.0f, -1.0f, {na})")
+        return self.new(f"cf_fma_swap({nb}, -1.0f, 1.0f, {na})")      # a + i b
+
     def add(self, a, b):
-        return (self.new(f"{a[0]} + {b[0]}"), self.new(f"{a[1]} + {b[1]}"))
+        (na, ra), (nb, rb) = a, b
+        return (self._add_rot(na, nb, rb - ra), ra % 4)
 
     def sub(self, a, b):
-        return (self.new(f"{a[0]} - {b[0]}"), self.new(f"{a[1]} - {b[1]}"))
+        (na, ra), (nb, rb) = a, b
+        return (self._add_rot(na, nb, rb - ra + 2), ra % 4)
 
-    def neg_i(self, a):           # a * (-i) = (im, -re)
-        return (a[1], f"(-{a[0]})")
+    def neg_i(self, a):
+        return (a[0], (a[1] + 1) % 4)
 
-    def pos_i(self, a):           # a * (+i) = (-im, re)
-        return (f"(-{a[1]})", a[0])
+    def pos_i(self, a):
+        return (a[0], (a[1] + 3) % 4)
 
     def scale(self, a, s):        # real scalar
-        return (self.new(f"{lit(s)} * {a[0]}"), self.new(f"{lit(s)} * {a[1]}"))
+        return (self.new(f"cf_scale({a[0]}, {lit(s)})"), a[1])
 
-    def axpy(self, s, a, b):      # s*a + b (complex a,b ; real s)
-        return (self.new(f"fmaf({lit(s)}, {a[0]}, {b[0]})", 2), self.new(f"fmaf({lit(s)}, {a[1]}, {b[1]})", 2))
+    def axpy(self, s, a, b):      # s*a + b (complex a, b; real s)
+        (na, ra), (nb, rb) = a, b
+        k = (ra - rb) % 4         # value = (-i)^rb (nb + s (-i)^k na)
+        if k == 0:
+            return (self.new(f"cf_fma_splat({na}, {lit(s)}, {nb})"), rb)
+        if k == 2:
+            return (self.new(f"cf_fma_splat({na}, {lit(-s)}, {nb})"), rb)
+        if k == 1:                # s (-i) a = s (a.y, -a.x)
+            return (self.new(f"cf_fma_swap({na}, {lit(s)}, {lit(-s)}, {nb})"), rb)
+        return (self.new(f"cf_fma_swap({na}, {lit(-s)}, {lit(s)}, {nb})"), rb)
 
     def mul_const(self, a, w: complex):
-        wr, wi = w.real, w.imag
+        na, ra = a
         eps = 1e-12
-        if abs(wr - 1) < eps and abs(wi) < eps:
-            return a
-        if abs(wr + 1) < eps and abs(wi) < eps:
-            return (f"(-{a[0]})", f"(-{a[1]})")
-        if abs(wr) < eps and abs(wi + 1) < eps:
-            return self.neg_i(a)
-        if abs(wr) < eps and abs(wi - 1) < eps:
-            return self.pos_i(a)
-        if abs(abs(wr) - abs(wi)) < eps:            # 45-degree family: s*(+-1 +- i)
-            s = abs(wr)
-            sr = 1.0 if wr > 0 else -1.0
-            si = 1.0 if wi > 0 else -1.0
-            # (ar + i ai) * s (sr + i si) = s[(sr ar - si ai) + i (si ar + sr ai)]
-            re = self.new(f"{lit(s)} * ({'' if sr > 0 else '-'}{a[0]} {'-' if si > 0 else '+'} {a[1]})", 2)
-            im = self.new(f"{lit(s)} * ({'' if si > 0 else '-'}{a[0]} {'+' if sr > 0 else '-'} {a[1]})", 2)
-            return (re, im)
-        re = self.new(f"fmaf({lit(wr)}, {a[0]}, {lit(-wi)} * {a[1]})", 3)
-        im = self.new(f"fmaf({lit(wr)}, {a[1]}, {lit(wi)} * {a[0]})", 3)
-        return (re, im)
+        for k, r in ROT.items():
+            if abs(w - r) < eps:
+                return (na, (ra + k) % 4)
+        # (x + i y)(c + i d) = (x c - y d, y c + x d) = fma(swap(a), (-d, d), a * c)
+        t = self.new(f"cf_scale({na}, {lit(w.real)})")
+        return (self.new(f"cf_fma_swap({na}, {lit(-w.imag)}, {lit(w.imag)}, {t})"), ra)
+
+    def plain(self, a):
+        """Materialise a pending rotation (only the outputs of a routine need it)."""
+        na, ra = a
+        ra %= 4
+        if ra == 0:
+            return na
+        if ra == 2:
+            return self.new(f"cf_scale({na}, -1.0f)")
+        if ra == 1:               # (-i)(x, y) = (y, -x)
+            return self.new(f"cf_mul_swap({na}, 1.0f, -1.0f)")
+        return self.new(f"cf_mul_swap({na}, -1.0f, 1.0f)")
 
     # -- butterflies -----------------------------------------------------------------
     def dft2(self, x):
@@ -96,7 +125,6 @@ class Emitter:
         m1 = self.axpy(-0.5, t1, x[0])
         d = self.sub(x[1], x[2])
         m2 = self.neg_i(self.scale(d, s))           # -i*s*(x1-x2)
-        m2 = (self.new(f"{m2[0]}", 0), self.new(f"{m2[1]}", 0))
         return [y0, self.add(m1, m2), self.sub(m1, m2)]
 
     def dft5(self, x):
@@ -111,13 +139,9 @@ class Emitter:
         p2 = self.axpy(c1, c, self.axpy(c2, a, x[0]))
         q1 = self.axpy(s2, d, self.scale(b, s1))     # s1 b + s2 d
         q2 = self.axpy(-s1, d, self.scale(b, s2))    # s2 b - s1 d
-        iq1 = (self.new(f"-{q1[1]}", 0), q1[0])      # +i*q1
-        iq2 = (self.new(f"-{q2[1]}", 0), q2[0])
-        y1 = self.sub(p1, iq1)
-        y4 = self.add(p1, iq1)
-        y2 = self.sub(p2, iq2)
-        y3 = self.add(p2, iq2)
-        return [y0, y1, y2, y3, y4]
+        iq1 = self.pos_i(q1)
+        iq2 = self.pos_i(q2)
+        return [y0, self.sub(p1, iq1), self.sub(p2, iq2), self.add(p2, iq2), self.add(p1, iq1)]
 
     # -- composite -------------------------------------------------------------------
     def dft(self, x):
@@ -158,7 +182,6 @@ class Emitter:
         inv2 = pow(n2, -1, n1)
         inv1 = pow(n1, -1, n2)
         grid = [[x[(n2 * a + n1 * b) % n] for b in range(n2)] for a in range(n1)]
-        # transform along a (size n1) for each b
         cols = [self.dft([grid[a][b] for a in range(n1)]) for b in range(n2)]       # [b][k1]
         out = [None] * n
         for k1 in range(n1):
@@ -170,31 +193,27 @@ class Emitter:
 
 def gen_function(n: int) -> tuple[str, int]:
     e = Emitter()
-    x = [(f"re[{i}]", f"im[{i}]") for i in range(n)]
-    # read inputs into named temporaries first so in-place use is safe
-    xin = [(e.new(a, 0), e.new(b, 0)) for a, b in x]
+    xin = [(f"z[{i}]", 0) for i in range(n)]
     y = e.dft(xin)
+    names = [e.plain(v) for v in y]
     body = "\n".join(e.lines)
-    stores = "\n".join(f"  re[{k}] = {y[k][0]};\n  im[{k}] = {y[k][1]};" for k in range(n))
-    src = (f"// {n}-point forward DFT, in place, natural order in and out ({e.flops} flops)\n"
-           f"SELD_HD void dft{n}(float (&re)[{n}], float (&im)[{n}]) {{\n{body}\n{stores}\n}}\n")
-    return src, e.flops
+    stores = "\n".join(f"  z[{k}] = {names[k]};" for k in range(n))
+    src = (f"// {n}-point forward DFT, in place, natural order in and out ({e.ops} packed operations)\n"
+           f"SELD_HD void dft{n}(cf (&z)[{n}]) {{\n{body}\n{stores}\n}}\n")
+    return src, e.ops
 
 
 def main():
     parts = []
     for n in (32, 30):
-        src, flops = gen_function(n)
+        src, ops = gen_function(n)
         parts.append(src)
-        print(f"dft{n}: {flops} flops")
+        print(f"dft{n}: {ops} packed operations")
     header = (
         "// GENERATED by tools/gen_fft.py -- do not edit by hand.\n"
         "// Straight-line in-register DFTs for the 960 = 32 x 30 point STFT of the log-mel kernel.\n"
         "#pragma once\n"
-        "#include <math.h>\n"
-        "#ifndef SELD_HD\n"
-        "#if defined(__HIPCC__)\n#define SELD_HD __host__ __device__ __forceinline__\n"
-        "#else\n#define SELD_HD inline\n#endif\n#endif\n\n"
+        "#include \"seld_complex.h\"\n\n"
         "namespace seld {\n\n" + "\n".join(parts) + "\n}  // namespace seld\n")
     OUT.write_text(header)
     print("wrote", OUT)
