@@ -65,6 +65,14 @@ int seld_logmel_f32_strided(const float* pcm, int64_t N, int64_t C, int64_t L, f
 int seld_logmel_i16_strided(const int16_t* pcm, int64_t N, int64_t C, int64_t L, float* out, int64_t sN, int64_t sC,
                             int64_t sM, int64_t sT, void* stream);
 
+/* The strided log-mel pass that ALSO writes the spectra it squares, spec_complex [N][C][F][481] complex64 (what
+ * seld_stft_* returns): the spatial features below read them, and one pass over the PCM serves both (north-star
+ * additions A14-A16; the reference has no such call -- its STFT lives inside torchaudio, dataset.py:27-58). */
+int seld_logmel_spectrum_f32(const float* pcm, int64_t N, int64_t C, int64_t L, float* out, int64_t sN, int64_t sC,
+                             int64_t sM, int64_t sT, float* spec_complex, void* stream);
+int seld_logmel_spectrum_i16(const int16_t* pcm, int64_t N, int64_t C, int64_t L, float* out, int64_t sN, int64_t sC,
+                             int64_t sM, int64_t sT, float* spec_complex, void* stream);
+
 /* ---- north-star additions without a reference implementation --------------
  * The reference computes its STFT only implicitly inside torchaudio and has no intensity-vector / GCC-PHAT
  * features; these entry points follow the DCASE SELD-baseline definitions.

@@ -36,6 +36,7 @@ N_FFT = 960         # config.py:85  int(0.04*24000)
 HOP = 480           # config.py:86  int(0.02*24000)
 N_MELS = 64         # config.py:87
 AMIN = 1e-10        # torchaudio AmplitudeToDB default
+GCC_SILENCE_POWER = 1e-12   # gcc_phat_f64: |X|^2 at or below this is a silent bin (north-star addition, no reference)
 
 
 def n_frames(num_samples: int, hop: int = HOP) -> int:
@@ -172,13 +173,21 @@ def foa_intensity_f64(pcm: np.ndarray, eps: float = 1e-8) -> np.ndarray:
 
 
 def gcc_phat_f64(pcm: np.ndarray, n_lags: int = N_MELS) -> np.ndarray:
-    """[C, L] -> [C(C-1)/2, 64, F]: cc = irfft(exp(1j*angle(conj(X_m) X_n))), lags -32..31."""
+    """[C, L] -> [C(C-1)/2, 64, F]: cc = irfft(exp(1j*angle(conj(X_m) X_n))), lags -32..31.
+    A bin of a SILENT channel has the phase factor 1.  Silent means |X|^2 <= GCC_SILENCE_POWER (1e-12: below the
+    noise floor of any recording, above what a transform that packs two frames leaves in an all-zero frame -- about
+    1e-7 of its neighbour's amplitude).  Without the rule numpy's angle() of a zero depends on the SIGNS of its zero
+    components (angle(-0.0 + 0j) = pi), an artefact no definition of the feature intends, and the phase of rounding
+    residue would be compared.  The kernel (csrc/spatial.hip) implements the same rule."""
     spec = stft_f64(pcm)                                            # [C, 481, F]
+    power = spec.real ** 2 + spec.imag ** 2
     c = spec.shape[0]
     out = []
     for m in range(c):
         for n in range(m + 1, c):
             r = np.conj(spec[m]) * spec[n]
-            cc = np.fft.irfft(np.exp(1j * np.angle(r)), n=N_FFT, axis=0)     # [960, F]
+            phase = np.exp(1j * np.angle(r))
+            phase[(power[m] <= GCC_SILENCE_POWER) | (power[n] <= GCC_SILENCE_POWER)] = 1.0
+            cc = np.fft.irfft(phase, n=N_FFT, axis=0)                       # [960, F]
             out.append(np.concatenate((cc[-n_lags // 2:], cc[:n_lags // 2]), axis=0))
     return np.stack(out)

@@ -19,6 +19,7 @@ struct LogmelArgs {
   long chunk;           // consecutive interior iterations per wavefront (main kernel)
   long sN, sC, sM, sT;  // output strides (elements): clip, channel, mel band, frame
   LogmelTables tab;
+  float* spec;          // kSpec instantiations: the un-packed spectra as well, [rows][F][481] complex64 (else unused)
 };
 
 __device__ __forceinline__ float* out_pointer(const LogmelArgs& a, long row, long itr, int lane) {
@@ -44,7 +45,9 @@ __device__ __forceinline__ void fill_tables(const LogmelArgs& a, float* tab, int
 // so nothing ever drains the memory queue (no vmcnt(0)), and the samples of the next iteration are requested
 // right after stage B -- into the registers the window multiply has just freed -- so their HBM latency is
 // covered by the un-packing / mel / store phases and by the SIMD's other wavefront.
-template <typename T>
+// kSpec: the spectra the power rows are formed from are also written out (frame-major rows of 481 complex) -- the spatial
+// features (csrc/spatial.hip) read them, and a second pass over the PCM through stft_kernel is not needed.
+template <typename T, bool kSpec>
 __global__ __launch_bounds__(kMainWaves * 64, 2) void logmel_main_kernel(LogmelArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
@@ -60,6 +63,8 @@ __global__ __launch_bounds__(kMainWaves * 64, 2) void logmel_main_kernel(LogmelA
   float* pp[16];
   power_row_pointers(lane, lds, a.tab.mel_pos, pp);
   __syncthreads();
+  LaneConsts consts;
+  load_lane_consts(lane, tab, consts);
 
   // Which iterations this wavefront runs is the same for its 64 lanes: with the wavefront index read through
   // readfirstlane the whole bookkeeping (row, iteration, clip / channel of the row, the division that starts it) lives in
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(kMainWaves * 64, 2) void logmel_main_kernel(LogmelA
       }
     }
     float* outp = out_lane + (clip * a.sN + chan * a.sC + itr * kFramesPerIter * a.sT);
-    phase_a(lane, s, tab, lds);
+    phase_a(lane, s, consts, lds);
     SELD_WAVE_SYNC();
     cf z[kN2];
     phase_b(lane, lds, z);
@@ -102,6 +107,10 @@ __global__ __launch_bounds__(kMainWaves * 64, 2) void logmel_main_kernel(LogmelA
     load_samples<T, true>(lane, pcm + nrow * a.L, a.L, nitr * kFramesPerIter + 2 * h, s);   // prefetch
     cf m[16];
     phase_c_load(lane, lds, m);
+    if (kSpec) {                                             // interior iterations: all four frames exist
+      float* base = a.spec + ((row * a.F + itr * kFramesPerIter) * kBins) * 2 + h * (2 * 2 * kBins);
+      phase_c_spectrum(lane, z, m, base, base + 2 * kBins);
+    }
     phase_c_store(lane, pp, z, m);
     SELD_WAVE_SYNC();
     LaneAcc acc;
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(kMainWaves * 64, 2) void logmel_main_kernel(LogmelA
 // ---- Edge kernel: the first iteration of every row (reflection on the left) and the last one or two
 // (reflection on the right, frames past the end masked).  One wavefront per edge iteration, no pipelining:
 // rows * edge_per_row iterations in total (256 for 32 one-minute clips) against ~96 000 interior ones.
-template <typename T>
+template <typename T, bool kSpec>
 __global__ __launch_bounds__(kEdgeWaves * 64, 1) void logmel_edge_kernel(LogmelArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
@@ -136,6 +145,8 @@ __global__ __launch_bounds__(kEdgeWaves * 64, 1) void logmel_edge_kernel(LogmelA
   float* pp[16];
   power_row_pointers(lane, lds, a.tab.mel_pos, pp);
   __syncthreads();
+  LaneConsts consts;
+  load_lane_consts(lane, tab, consts);
 
   const long e = static_cast<long>(blockIdx.x) * kEdgeWaves + wave;
   if (e >= a.rows * a.edge_per_row) return;
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(kEdgeWaves * 64, 1) void logmel_edge_kernel(LogmelA
 
   float s[48];
   load_samples<T, false>(lane, pcm + row * a.L, a.L, tf + 2 * h, s);
-  phase_a(lane, s, tab, lds);
+  phase_a(lane, s, consts, lds);
   SELD_WAVE_SYNC();
   cf z[kN2];
   phase_b(lane, lds, z);
@@ -156,6 +167,11 @@ __global__ __launch_bounds__(kEdgeWaves * 64, 1) void logmel_edge_kernel(LogmelA
   SELD_WAVE_SYNC();
   cf m[16];
   phase_c_load(lane, lds, m);
+  if (kSpec) {
+    const long fa = tf + 2 * h;
+    float* base = a.spec + (row * a.F + fa) * (2 * kBins);
+    phase_c_spectrum(lane, z, m, fa < a.F ? base : nullptr, fa + 1 < a.F ? base + 2 * kBins : nullptr);
+  }
   phase_c_store(lane, pp, z, m);
   SELD_WAVE_SYNC();
   LaneAcc acc;
@@ -185,6 +201,8 @@ __global__ __launch_bounds__(kEdgeWaves * 64, 2) void stft_kernel(LogmelArgs a) 
   fill_tables(a, tab, tid, kEdgeWaves * 64);
   for (int i = lane; i < kLdsFloatsPerWave; i += 64) lds[i] = 0.0f;
   __syncthreads();
+  LaneConsts consts;
+  load_lane_consts(lane, tab, consts);
 
   const long total = a.rows * a.iters_per_row;
   const long gw = static_cast<long>(blockIdx.x) * kEdgeWaves + wave;
@@ -200,7 +218,7 @@ __global__ __launch_bounds__(kEdgeWaves * 64, 2) void stft_kernel(LogmelArgs a) 
     float s[48];
     if (interior) load_samples<T, true>(lane, pcm + row * a.L, a.L, tf + 2 * h, s);
     else load_samples<T, false>(lane, pcm + row * a.L, a.L, tf + 2 * h, s);
-    phase_a(lane, s, tab, lds);
+    phase_a(lane, s, consts, lds);
     SELD_WAVE_SYNC();
     cf z[kN2];
     phase_b(lane, lds, z);
@@ -256,12 +274,12 @@ static int launch_stft(const T* pcm, int64_t N, int64_t C, int64_t L, float* out
   return kOk;
 }
 
-template <typename T>
+template <typename T, bool kSpec = false>
 static int launch_logmel(const T* pcm, int64_t N, int64_t C, int64_t L, float* out, int layout,
-                         hipStream_t stream, const int64_t* strides = nullptr) {
+                         hipStream_t stream, const int64_t* strides = nullptr, float* spec = nullptr) {
   DeviceState* st = current_state();
   if (!st) return kErrNotInitialised;
-  if (!pcm || !out) return fail(kErrInvalidArgument, "seld_logmel: null pointer");
+  if (!pcm || !out || (kSpec && !spec)) return fail(kErrInvalidArgument, "seld_logmel: null pointer");
   if (N <= 0 || C <= 0) return fail(kErrInvalidArgument, "seld_logmel: N and C must be positive");
   if (L <= kNfft / 2)
     return fail(kErrInvalidArgument, "seld_logmel: reflect padding needs L > n_fft/2 = 480 samples");
@@ -299,12 +317,14 @@ static int launch_logmel(const T* pcm, int64_t N, int64_t C, int64_t L, float* o
   }
   a.tab = st->tables();
   a.chunk = 1;
+  a.spec = spec;
 
-  const unsigned bit = sizeof(T) == 4 ? kAttrLogmelF32 : kAttrLogmelI16;
+  const unsigned bit = kSpec ? (sizeof(T) == 4 ? kAttrLogmelSpecF32 : kAttrLogmelSpecI16)
+                             : (sizeof(T) == 4 ? kAttrLogmelF32 : kAttrLogmelI16);
   if (need_lds(st, bit)) {                 // once per device (seld_common.h)
-    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_main_kernel<T>),
+    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_main_kernel<T, kSpec>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, kMainLdsBytes));
-    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_edge_kernel<T>),
+    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_edge_kernel<T, kSpec>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, kEdgeLdsBytes));
     lds_attr_set(st, bit);
   }
@@ -319,7 +339,7 @@ static int launch_logmel(const T* pcm, int64_t N, int64_t C, int64_t L, float* o
     SELD_HIP_TRY(hipEventRecord(st->fork_event, stream));
     SELD_HIP_TRY(hipStreamWaitEvent(st->side_stream, st->fork_event, 0));
   }
-  hipLaunchKernelGGL(logmel_edge_kernel<T>, dim3(static_cast<unsigned>((n_edge + kEdgeWaves - 1) / kEdgeWaves)),
+  hipLaunchKernelGGL((logmel_edge_kernel<T, kSpec>), dim3(static_cast<unsigned>((n_edge + kEdgeWaves - 1) / kEdgeWaves)),
                      dim3(kEdgeWaves * 64), kEdgeLdsBytes, edge_stream, a);
   SELD_HIP_TRY(hipGetLastError());
   if (total > 0) {
@@ -330,7 +350,7 @@ static int launch_logmel(const T* pcm, int64_t N, int64_t C, int64_t L, float* o
     a.chunk = (total + waves - 1) / waves;
     const long used_waves = (total + a.chunk - 1) / a.chunk;
     const long grid = (used_waves + kMainWaves - 1) / kMainWaves;
-    hipLaunchKernelGGL(logmel_main_kernel<T>, dim3(static_cast<unsigned>(grid)), dim3(kMainWaves * 64), kMainLdsBytes,
+    hipLaunchKernelGGL((logmel_main_kernel<T, kSpec>), dim3(static_cast<unsigned>(grid)), dim3(kMainWaves * 64), kMainLdsBytes,
                        stream, a);
     SELD_HIP_TRY(hipGetLastError());
     SELD_HIP_TRY(hipEventRecord(st->join_event, st->side_stream));
@@ -361,6 +381,18 @@ int seld_logmel_i16_strided(const int16_t* pcm, int64_t N, int64_t C, int64_t L,
                             int64_t sM, int64_t sT, void* stream) {
   const int64_t strides[4] = {sN, sC, sM, sT};
   return seld::launch_logmel<int16_t>(pcm, N, C, L, out, 0, static_cast<hipStream_t>(stream), strides);
+}
+
+int seld_logmel_spectrum_f32(const float* pcm, int64_t N, int64_t C, int64_t L, float* out, int64_t sN, int64_t sC,
+                             int64_t sM, int64_t sT, float* spec_complex, void* stream) {
+  const int64_t strides[4] = {sN, sC, sM, sT};
+  return seld::launch_logmel<float, true>(pcm, N, C, L, out, 0, static_cast<hipStream_t>(stream), strides, spec_complex);
+}
+
+int seld_logmel_spectrum_i16(const int16_t* pcm, int64_t N, int64_t C, int64_t L, float* out, int64_t sN, int64_t sC,
+                             int64_t sM, int64_t sT, float* spec_complex, void* stream) {
+  const int64_t strides[4] = {sN, sC, sM, sT};
+  return seld::launch_logmel<int16_t, true>(pcm, N, C, L, out, 0, static_cast<hipStream_t>(stream), strides, spec_complex);
 }
 
 int seld_stft_f32(const float* pcm, int64_t N, int64_t C, int64_t L, float* out_complex, void* stream) {

@@ -143,27 +143,45 @@ SELD_HD void load_samples(int lane, const T* row, long L, long fa, float (&s)[48
   }
 }
 
-// Tail of stage A: multiply the 32-pt DFT outputs by the two-level twiddles W_960^{n2*k1} = hi[k1>>3]*lo[k1&7]
-// (`tw_lane` = this lane's quad in the twiddle table rows: [5][64][4] floats, row v at +256 v) and store
-// column l of this half-wavefront's [32][31]-complex exchange tile (one 8-byte store per element).
-SELD_HD void stage_a_finish(int lane, const cf (&z)[kN1], const float* tw_lane, float* lds) {
-  const int h = lane >> 5;
-  const int l = lane & 31;
-  cf tw[10];
+// Per-lane constants of stage A, read once per wavefront from the workgroup's table block and kept in registers
+// across the iterations (32 VGPRs; round 1 re-read them from LDS every iteration because its 234-VGPR body had no room:
+// 8 of the ~105 KB of LDS traffic per wavefront-iteration).
+struct LaneConsts {
+  float win[kN1];     // 0.5 * Hann at 30 n1 + n2
+  const float* twq;   // this lane's quad of the twiddle rows ([5][64][4] floats, row v at +256 v): lo[1..7] = W_960^{n2 b},
+                      // hi[1..3] = W_960^{n2 8 a} -- re-read every iteration (with them the body spills)
+};
+
+SELD_HD void load_twiddles(const float* twq, cf (&tw)[10]) {
 #pragma unroll
   for (int v = 0; v < 5; ++v) {
-    tw[2 * v] = cf_make(tw_lane[v * 256], tw_lane[v * 256 + 1]);
-    tw[2 * v + 1] = cf_make(tw_lane[v * 256 + 2], tw_lane[v * 256 + 3]);
+    tw[2 * v] = cf_make(twq[v * 256], twq[v * 256 + 1]);
+    tw[2 * v + 1] = cf_make(twq[v * 256 + 2], twq[v * 256 + 3]);
   }
+}
+
+SELD_HD void load_lane_consts(int lane, const float* tab, LaneConsts& k) {
+  const float* tl = tab + lane * 4;                    // this lane's quad in every table row
+#pragma unroll
+  for (int n1 = 0; n1 < kN1; ++n1) k.win[n1] = tl[kTabWin + (n1 >> 2) * 256 + (n1 & 3)];
+  k.twq = tl + kTabTw;
+}
+
+// Tail of stage A: multiply the 32-pt DFT outputs by the two-level twiddles W_960^{n2*k1} = hi[k1>>3]*lo[k1&7] and store
+// column l of this half-wavefront's [32][31]-complex exchange tile (one 8-byte store per element).
+SELD_HD void stage_a_finish(int lane, const cf (&z)[kN1], const cf (&tw)[10], float* lds) {
+  const int h = lane >> 5;
+  const int l = lane & 31;
   if (l < kN2) {
     float* e = lds + e_index(h, 0, l);                 // column l of this half's tile; row k1 is at +62*k1
+    // lo twiddles for all 32, then hi twiddles: consecutive products are independent of each other
+    cf y[kN1];
+#pragma unroll
+    for (int k1 = 0; k1 < kN1; ++k1) y[k1] = (k1 & 7) != 0 ? cf_cmul(z[k1], tw[(k1 & 7) - 1]) : z[k1];
 #pragma unroll
     for (int k1 = 0; k1 < kN1; ++k1) {
-      const int a = k1 >> 3, b = k1 & 7;
-      cf y = z[k1];
-      if (b != 0) y = cf_cmul(y, tw[b - 1]);
-      if (a != 0) y = cf_cmul(y, tw[6 + a]);
-      *reinterpret_cast<cf*>(e + k1 * kEPitch * 2) = y;
+      if ((k1 >> 3) != 0) y[k1] = cf_cmul(y[k1], tw[6 + (k1 >> 3)]);
+      *reinterpret_cast<cf*>(e + k1 * kEPitch * 2) = y[k1];
     }
   }
 }
@@ -174,23 +192,17 @@ SELD_HD void stage_a_finish(int lane, const cf (&z)[kN1], const float* tw_lane, 
 // every distinct constant (dozens of VGPRs, which then spill).
 
 // ---- Phase A: window, pack two frames, 32-pt DFT, twiddle, LDS column store.
-SELD_HD void phase_a(int lane, const float (&s)[48], const float* tab, float* lds) {
-  const int h = lane >> 5;
-  const int l = lane & 31;
-  const float* tl = tab + lane * 4;                    // this lane's quad in every table row
+SELD_HD void phase_a(int lane, const float (&s)[48], const LaneConsts& k, float* lds) {
   cf z[kN1];
 #pragma unroll
-  for (int qd = 0; qd < 8; ++qd) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n1 = 4 * qd + j;
-      const float w = tl[kTabWin + qd * 256 + j];        // 0.5 * Hann (see table_value)
-      // frame fa -> real part, frame fa+1 (the same samples shifted by 480 = 16*30) -> imaginary part
-      z[n1] = cf_make(w * s[n1], w * s[n1 + 16]);
-    }
+  for (int n1 = 0; n1 < kN1; ++n1) {
+    // frame fa -> real part, frame fa+1 (the same samples shifted by 480 = 16*30) -> imaginary part
+    z[n1] = cf_make(k.win[n1] * s[n1], k.win[n1] * s[n1 + 16]);
   }
   dft32(z);
-  stage_a_finish(lane, z, tl + kTabTw, lds);
+  cf tw[10];
+  load_twiddles(k.twq, tw);
+  stage_a_finish(lane, z, tw, lds);
 }
 
 // ---- Phase B: 30-pt DFT along n2 for row k1 = l, then park the upper half-spectrum for the mirror read.
@@ -279,13 +291,16 @@ SELD_HD void phase_d_accumulate(int lane, float* lds, const float* tab, int seg,
     cf w[4];                       // (wd, wu) of bins 4 iq .. 4 iq + 3 of this lane's segment: pairs as the table stores them
 #pragma unroll
     for (int k = 0; k < 4; ++k) w[k] = cf_make(tl[(2 * iq + (k >> 1)) * 256 + 2 * (k & 1)], tl[(2 * iq + (k >> 1)) * 256 + 2 * (k & 1) + 1]);
+    PowerQuad q[kFramesPerIter];                               // one ds_read_b128 each, conflict free (see kPPitch)
 #pragma unroll
-    for (int s = 0; s < kFramesPerIter; ++s) {
-      const PowerQuad q = p[s * (kPPitch / 4) + iq];           // one ds_read_b128, conflict free (see kPPitch)
+    for (int s = 0; s < kFramesPerIter; ++s) q[s] = p[s * (kPPitch / 4) + iq];
+    // bins in ascending order for every sum; the four frames' chains interleaved (a packed op that consumes the result of
+    // the packed op right before it costs a wait state)
 #pragma unroll
-      for (int k = 0; k < 4; ++k)                              // bins in ascending order; both sums in one packed fma
-        acc.ab[s] = cf_fma(w[k], cf_make(q.p[k], q.p[k]), acc.ab[s]);
-    }
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int s = 0; s < kFramesPerIter; ++s)
+        acc.ab[s] = cf_fma(w[k], cf_make(q[s].p[k], q[s].p[k]), acc.ab[s]);
   }
   float* bs = lds + kBsOff + lane;
 #pragma unroll

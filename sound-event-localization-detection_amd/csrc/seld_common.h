@@ -57,6 +57,8 @@ enum LdsAttrBit : unsigned {
   kAttrLogmelF32 = 1u << 4,
   kAttrLogmelI16 = 1u << 5,
   kAttrSpatial = 1u << 6,
+  kAttrLogmelSpecF32 = 1u << 7,
+  kAttrLogmelSpecI16 = 1u << 8,
 };
 
 // true when `bit` still has to be set up on this device (the caller then sets its attributes and calls lds_attr_set)

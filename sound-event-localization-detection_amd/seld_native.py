@@ -54,6 +54,9 @@ def _declare(lib):
     for name in ("seld_stft_f32", "seld_stft_i16"):
         getattr(lib, name).argtypes = [_ptr, _i64, _i64, _i64, _ptr, _ptr]
     lib.seld_foa_intensity.argtypes = [_ptr, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr]
+    for fn in (lib.seld_logmel_spectrum_f32, lib.seld_logmel_spectrum_i16):
+        fn.argtypes = [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr]
+        fn.restype = ctypes.c_int
     lib.seld_gcc_phat.argtypes = [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr]
     lib.seld_labels_rasterise.argtypes = [_ptr, _i64, _i64, _int, _int, _ptr, _ptr]
     lib.seld_labels_expand.argtypes = [_ptr, _i64, _int, _ptr, _ptr]
@@ -887,9 +890,10 @@ def spatial_features(pcm: torch.Tensor, kind: str) -> torch.Tensor:
     lib = load_library()
     stream = _stream_ptr(pcm.device)
     with _device_guard(index):
-        fn = lib.seld_logmel_f32_strided if pcm.dtype == torch.float32 else lib.seld_logmel_i16_strided
-        check(fn(_p(pcm), n, c, length, _p(out), s_n, s_c, s_m, s_t, stream), "seld_logmel_strided")
-        spec = torch.view_as_real(stft(pcm))                                  # [N, C, F, 481, 2]
+        # one pass over the PCM: the log-mel channels and the spectra the spatial kernels read
+        spec = torch.empty((n, c, frames, N_FFT // 2 + 1, 2), dtype=torch.float32, device=pcm.device)
+        fn = lib.seld_logmel_spectrum_f32 if pcm.dtype == torch.float32 else lib.seld_logmel_spectrum_i16
+        check(fn(_p(pcm), n, c, length, _p(out), s_n, s_c, s_m, s_t, _p(spec), stream), "seld_logmel_spectrum")
         tail = ctypes.c_void_p(out.data_ptr() + c * N_MELS * 4)              # channel offset c
         if kind == "logmel_iv":
             check(lib.seld_foa_intensity(_p(spec), n, frames, tail, s_n, s_c, s_m, s_t, stream), "seld_foa_intensity")

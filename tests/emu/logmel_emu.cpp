@@ -64,8 +64,11 @@ int run(const T* pcm, int64_t N, int64_t C, int64_t L, float* out, int layout, c
         if (interior) load_samples<T, true>(lane, rowp, L, fa, s);
         else load_samples<T, false>(lane, rowp, L, fa, s);
       }
-      for (int lane = 0; lane < 64; ++lane)
-        phase_a(lane, *reinterpret_cast<float(*)[48]>(&smp[lane * 48]), tab_lds.data(), lds.data());
+      for (int lane = 0; lane < 64; ++lane) {
+        LaneConsts consts;
+        load_lane_consts(lane, tab_lds.data(), consts);
+        phase_a(lane, *reinterpret_cast<float(*)[48]>(&smp[lane * 48]), consts, lds.data());
+      }
       for (int lane = 0; lane < 64; ++lane)
         phase_b(lane, lds.data(), *reinterpret_cast<cf(*)[kN2]>(&z[lane * kN2]));
       for (int lane = 0; lane < 64; ++lane)

@@ -67,3 +67,21 @@ def test_batched_spatial_features(gpu_device):
     for i in range(3):
         assert torch.equal(iv[i], seld_native.spatial_features(pcm[i], "logmel_iv"))
         assert torch.equal(gcc[i], seld_native.spatial_features(pcm[i], "logmel_gcc"))
+
+
+def test_gcc_phat_with_a_silent_channel(gpu_device):
+    """X = 0 must give R / |R| = 1 (np.exp(1j * np.angle(0))): pairs with the dead microphone are a unit pulse at lag 0,
+    the other pairs are untouched.  (The kernel stores a zero phasor for such a channel and switches, per frame, to the
+    variant that turns zero products into 1 -- csrc/spatial.hip.)"""
+    import seld_native
+    pcm = ofeat.synth_pcm(11, 4, 9600 + 5, "noise")
+    pcm[2] = 0.0
+    pcm[:, 4800:6000] = 0.0                                               # and a stretch of digital silence in all of them
+    feat = seld_native.spatial_features(pcm.to(gpu_device), "logmel_gcc").cpu()
+    ref = ofeat.gcc_phat_f64(pcm.numpy())                                 # [6, 64, F]
+    got = feat[:, 4:].permute(1, 2, 0).numpy()
+    assert np.abs(got - ref).max() <= 1e-4
+    dead = [1, 3, 5]                                                      # pairs (0,2), (1,2), (2,3) in lexicographic order
+    pulse = np.zeros(64)
+    pulse[32] = 1.0
+    assert np.abs(got[dead] - pulse[None, :, None]).max() <= 1e-4
