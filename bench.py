@@ -297,6 +297,21 @@ def kernel_rooflines(device):
     tm = torch.zeros(BATCH * HOP + WINDOW, 648, dtype=torch.uint16, device=device)
     hbm("seld::gather_rows_kernel (label mask windows)", 2 * BATCH * WINDOW * 648 * 2,
         timeit(lambda: nat.gather_windows(tm, starts, WINDOW)))
+    # log-mel from int16 PCM (csrc/logmel.hip, the <int16_t> instantiation: 14.59 MB per 60 s clip) and the
+    # 8-channel MIC-array feature pass (log-mel + spectra in one pass, then csrc/spatial.hip gcc_phat_kernel):
+    # 8 x 5.76 MB PCM in + 36 x 64 x 3001 x 4 B out per clip
+    clips = 8
+    pcm16 = (torch.randn(clips, CHANNELS, CLIP_SAMPLES, device=device) * 3276.8).clamp(-32768, 32767).to(torch.int16)
+    lm_out = torch.empty(clips, 1 + CLIP_SAMPLES // 480, CHANNELS, 64, device=device)
+    hbm(f"seld::logmel_main_kernel<int16_t> + edge ({clips} clips, int16 PCM)",
+        clips * (CHANNELS * CLIP_SAMPLES * 2 + lm_out[0].numel() * 4),
+        timeit(lambda: nat.logmel(pcm16, layout="tcf", out=lm_out), reps=5))
+    del pcm16, lm_out
+    pcm8 = torch.randn(clips, 8, CLIP_SAMPLES, device=device) * 0.1
+    hbm(f"spatial_features logmel_gcc ({clips} clips x 8 ch: logmel_main_kernel<float, true> + gcc_phat_kernel)",
+        clips * (8 * CLIP_SAMPLES * 4 + 36 * 64 * (1 + CLIP_SAMPLES // 480) * 4),
+        timeit(lambda: nat.spatial_features(pcm8, "logmel_gcc"), reps=3))
+    del pcm8
     # GRU recurrence (csrc/gru.hip)
     h = 256
     gi = (torch.randn(BATCH, WINDOW, 2, 3 * h, device=device) * 0.5).to(torch.bfloat16)
