@@ -20,6 +20,7 @@ struct LogmelArgs {
   long sN, sC, sM, sT;  // output strides (elements): clip, channel, mel band, frame
   LogmelTables tab;
   float* spec;          // kSpec instantiations: the un-packed spectra as well, [rows][F][481] complex64 (else unused)
+  long main_blocks;     // main kernel: workgroups [0, main_blocks) run interior pipelines, the rest edge iterations
 };
 
 __device__ __forceinline__ float* out_pointer(const LogmelArgs& a, long row, long itr, int lane) {
@@ -37,6 +38,47 @@ __device__ __forceinline__ void fill_tables(const LogmelArgs& a, float* tab, int
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
     __builtin_amdgcn_wave_barrier();                       \
   } while (0)
+
+// One edge iteration (index e of rows * edge_per_row) by one wavefront: generic load path (reflection, frames past the end
+// masked), no pipelining.
+template <typename T, bool kSpec>
+__device__ __forceinline__ void edge_iteration(const LogmelArgs& a, long e, int lane, const float* tab, float* lds, int seg,
+                                               float* const (&pp)[16], const LaneConsts& consts) {
+  const int h = lane >> 5;
+  const long row = e / a.edge_per_row;
+  const long j = e - row * a.edge_per_row;
+  const long itr = a.interior >= 1 ? (j == 0 ? 0 : a.interior + j) : j;
+  const long tf = itr * kFramesPerIter;
+  const T* pcm = static_cast<const T*>(a.pcm);
+
+  float s[48];
+  load_samples<T, false>(lane, pcm + row * a.L, a.L, tf + 2 * h, s);
+  phase_a(lane, s, consts, lds);
+  SELD_WAVE_SYNC();
+  cf z[kN2];
+  phase_b(lane, lds, z);
+  SELD_WAVE_SYNC();
+  phase_b_store(lane, lds, z);
+  SELD_WAVE_SYNC();
+  cf m[16];
+  phase_c_load(lane, lds, m);
+  if (kSpec) {
+    const long fa = tf + 2 * h;
+    float* base = a.spec + (row * a.F + fa) * (2 * kBins);
+    phase_c_spectrum(lane, z, m, fa < a.F ? base : nullptr, fa + 1 < a.F ? base + 2 * kBins : nullptr);
+  }
+  phase_c_store(lane, pp, z, m);
+  SELD_WAVE_SYNC();
+  LaneAcc acc;
+  phase_d_accumulate(lane, lds, tab, seg, acc);
+  SELD_WAVE_SYNC();
+  float db[kFramesPerIter];
+  phase_d_finish(lane, lds, acc, db);
+  float* outp = out_pointer(a, row, itr, lane);
+#pragma unroll
+  for (int f = 0; f < kFramesPerIter; ++f)
+    if (tf + f < a.F) outp[f * a.sT] = db[f];
+}
 
 // ---- Main kernel: the interior iterations of every row (all but the first and the last one or two).
 // One wavefront = one independent pipeline over a contiguous run of iterations; the 8 wavefronts of a
@@ -66,6 +108,15 @@ __global__ __launch_bounds__(kMainWaves * 64, 2) void logmel_main_kernel(LogmelA
   LaneConsts consts;
   load_lane_consts(lane, tab, consts);
 
+  // Workgroups past main_blocks run the edge iterations (the first and the last one or two of every row), 8 per
+  // workgroup: they land on the CUs the interior pipelines leave free and are done long before those are (round 1 ran
+  // them as a second kernel on a side stream; its workgroups could not share a CU's LDS with a main one, ran when the
+  // main kernel drained, and the fork / join events and the second launch were 13 % of the feature phase).
+  if (static_cast<long>(blockIdx.x) >= a.main_blocks) {
+    const long e = (static_cast<long>(blockIdx.x) - a.main_blocks) * kMainWaves + wave;
+    if (e < a.rows * a.edge_per_row) edge_iteration<T, kSpec>(a, e, lane, tab, lds, seg, pp, consts);
+    return;
+  }
   // Which iterations this wavefront runs is the same for its 64 lanes: with the wavefront index read through
   // readfirstlane the whole bookkeeping (row, iteration, clip / channel of the row, the division that starts it) lives in
   // scalar registers and the scalar unit; derived from threadIdx it was ~120 vector instructions of 64-bit division per
@@ -150,39 +201,7 @@ __global__ __launch_bounds__(kEdgeWaves * 64, 1) void logmel_edge_kernel(LogmelA
 
   const long e = static_cast<long>(blockIdx.x) * kEdgeWaves + wave;
   if (e >= a.rows * a.edge_per_row) return;
-  const long row = e / a.edge_per_row;
-  const long j = e - row * a.edge_per_row;
-  const long itr = a.interior >= 1 ? (j == 0 ? 0 : a.interior + j) : j;
-  const long tf = itr * kFramesPerIter;
-  const T* pcm = static_cast<const T*>(a.pcm);
-
-  float s[48];
-  load_samples<T, false>(lane, pcm + row * a.L, a.L, tf + 2 * h, s);
-  phase_a(lane, s, consts, lds);
-  SELD_WAVE_SYNC();
-  cf z[kN2];
-  phase_b(lane, lds, z);
-  SELD_WAVE_SYNC();
-  phase_b_store(lane, lds, z);
-  SELD_WAVE_SYNC();
-  cf m[16];
-  phase_c_load(lane, lds, m);
-  if (kSpec) {
-    const long fa = tf + 2 * h;
-    float* base = a.spec + (row * a.F + fa) * (2 * kBins);
-    phase_c_spectrum(lane, z, m, fa < a.F ? base : nullptr, fa + 1 < a.F ? base + 2 * kBins : nullptr);
-  }
-  phase_c_store(lane, pp, z, m);
-  SELD_WAVE_SYNC();
-  LaneAcc acc;
-  phase_d_accumulate(lane, lds, tab, seg, acc);
-  SELD_WAVE_SYNC();
-  float db[kFramesPerIter];
-  phase_d_finish(lane, lds, acc, db);
-  float* outp = out_pointer(a, row, itr, lane);
-#pragma unroll
-  for (int f = 0; f < kFramesPerIter; ++f)
-    if (tf + f < a.F) outp[f * a.sT] = db[f];
+  edge_iteration<T, kSpec>(a, e, lane, tab, lds, seg, pp, consts);
 }
 
 // ---- STFT export (north-star addition A14: the reference only has the STFT implicitly inside torchaudio).
@@ -330,32 +349,30 @@ static int launch_logmel(const T* pcm, int64_t N, int64_t C, int64_t L, float* o
   }
   const long n_edge = a.rows * a.edge_per_row;
   const long total = a.rows * a.interior;
-  // The edge kernel (a few hundred latency-bound wavefront-iterations) runs on the library's side stream,
-  // forked from and joined back into the caller's stream with events, so it overlaps the main kernel
-  // (same pattern under stream capture).
-  const bool fork = total > 0;
-  hipStream_t edge_stream = fork ? st->side_stream : stream;
-  if (fork) {
-    SELD_HIP_TRY(hipEventRecord(st->fork_event, stream));
-    SELD_HIP_TRY(hipStreamWaitEvent(st->side_stream, st->fork_event, 0));
-  }
-  hipLaunchKernelGGL((logmel_edge_kernel<T, kSpec>), dim3(static_cast<unsigned>((n_edge + kEdgeWaves - 1) / kEdgeWaves)),
-                     dim3(kEdgeWaves * 64), kEdgeLdsBytes, edge_stream, a);
-  SELD_HIP_TRY(hipGetLastError());
-  if (total > 0) {
-    // one 8-wavefront workgroup per CU (LDS bound); every wavefront gets a contiguous run of >= 8 iterations
-    const long max_waves = static_cast<long>(st->num_cus) * kMainWaves;
-    long waves = (total + 7) / 8;
-    if (waves > max_waves) waves = max_waves;
-    a.chunk = (total + waves - 1) / waves;
-    const long used_waves = (total + a.chunk - 1) / a.chunk;
-    const long grid = (used_waves + kMainWaves - 1) / kMainWaves;
-    hipLaunchKernelGGL((logmel_main_kernel<T, kSpec>), dim3(static_cast<unsigned>(grid)), dim3(kMainWaves * 64), kMainLdsBytes,
-                       stream, a);
+  a.main_blocks = 0;
+  if (total == 0) {             // clips shorter than ~8 frames: edge iterations only
+    hipLaunchKernelGGL((logmel_edge_kernel<T, kSpec>), dim3(static_cast<unsigned>((n_edge + kEdgeWaves - 1) / kEdgeWaves)),
+                       dim3(kEdgeWaves * 64), kEdgeLdsBytes, stream, a);
     SELD_HIP_TRY(hipGetLastError());
-    SELD_HIP_TRY(hipEventRecord(st->join_event, st->side_stream));
-    SELD_HIP_TRY(hipStreamWaitEvent(stream, st->join_event, 0));
+    return kOk;
   }
+  // ONE launch: one 8-wavefront workgroup per CU runs the interior pipelines (LDS bound; every wavefront gets a
+  // contiguous run of >= 8 iterations), and the edge iterations are the trailing workgroups of the same grid.  A few CUs
+  // are left to them so that they start at once and finish inside the main workgroups' lifetime.
+  const long edge_blocks = (n_edge + kMainWaves - 1) / kMainWaves;
+  long reserve = (edge_blocks + 7) / 8;                 // an edge workgroup lives ~1/25 of a full-length main one
+  if (reserve > 4) reserve = 4;
+  long cus = static_cast<long>(st->num_cus) - reserve;
+  if (cus < 1) cus = 1;
+  const long max_waves = cus * kMainWaves;
+  long waves = (total + 7) / 8;
+  if (waves > max_waves) waves = max_waves;
+  a.chunk = (total + waves - 1) / waves;
+  const long used_waves = (total + a.chunk - 1) / a.chunk;
+  a.main_blocks = (used_waves + kMainWaves - 1) / kMainWaves;
+  hipLaunchKernelGGL((logmel_main_kernel<T, kSpec>), dim3(static_cast<unsigned>(a.main_blocks + edge_blocks)),
+                     dim3(kMainWaves * 64), kMainLdsBytes, stream, a);
+  SELD_HIP_TRY(hipGetLastError());
   return kOk;
 }
 
