@@ -111,6 +111,7 @@ int seld_shutdown(void) {
     (void)hipFree(st.mel_wd);
     (void)hipFree(st.mel_wu);
     (void)hipFree(st.mel_fb);
+    if (st.gcc_table) (void)hipFree(st.gcc_table);
     (void)hipEventDestroy(st.fork_event);
     (void)hipEventDestroy(st.join_event);
     (void)hipStreamDestroy(st.side_stream);

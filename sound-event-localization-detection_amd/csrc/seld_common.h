@@ -40,6 +40,7 @@ struct DeviceState {
   float* mel_wu = nullptr;
   int* mel_pos = nullptr;       // power-row placement (logmel_tables.h, place_power_rows)
   float* mel_fb = nullptr;      // dense [481][64] copy (used by the intensity-vector / debug paths)
+  void* gcc_table = nullptr;    // fp16 cosine / sine B fragments of the matrix-core GCC-PHAT (spatial.hip), built on first use
   // side stream + fork/join events: the tiny edge kernel of the log-mel path overlaps the main kernel
   hipStream_t side_stream = nullptr;
   hipEvent_t fork_event = nullptr, join_event = nullptr;
@@ -59,6 +60,7 @@ enum LdsAttrBit : unsigned {
   kAttrSpatial = 1u << 6,
   kAttrLogmelSpecF32 = 1u << 7,
   kAttrLogmelSpecI16 = 1u << 8,
+  kAttrGccMfma = 1u << 9,
 };
 
 // true when `bit` still has to be set up on this device (the caller then sets its attributes and calls lds_attr_set)

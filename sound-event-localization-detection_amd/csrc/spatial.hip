@@ -13,6 +13,13 @@
 //
 // HBM-bound: 4 x 481 x 8 B = 15.4 KB of spectra read and 768 B written per frame (intensity vectors);
 // C x 3.8 KB read and C(C-1)/2 x 256 B written per frame (GCC).
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
 #include "seld_common.h"
 
 namespace seld {
@@ -298,6 +305,314 @@ __global__ __launch_bounds__(kGccThreads, 2) void gcc_phat_kernel(GccArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------- GCC-PHAT on the matrix cores
+// The 64 wanted lags of a pair are a SMALL dense transform of its 481 phase factors:
+//     cc[n] = (1/960) sum_k w_k ( Re R_k cos(2 pi k n / 960) - Im R_k sin(2 pi k n / 960) ),   w_0 = w_480 = 1, else 2
+// (irfft), so with  C[l] = sum_k Re R_k  w_k cos(theta_k l)  and  S[l] = sum_k Im R_k (-w_k sin(theta_k l)),  l = 0..32:
+//     cc[+l] = (C[l] + S[l]) / 960 ,    cc[-l] = (C[l] - S[l]) / 960 .
+// Per frame that is two GEMMs  [pairs x 481] x [481 x 33]  -- M = pairs (28 -> two 16-row tiles), N = lags (33 -> three
+// 16-column tiles), K = bins (481 -> 16 steps of 32) on v_mfma_f32_16x16x32_f16: the A fragments (Re R, Im R of 8
+// consecutive bins of one pair per lane) are formed in registers from the frame's fp32 phasors in LDS and rounded to fp16
+// once; the B fragments are a constant cosine / sine table (96 KB of fp16, fragment-major, staged in LDS once per
+// workgroup); accumulation in fp32.  Rounding: |R|, |cos| <= 1 in fp16 (2^-11 relative) over 2 x 481 terms of random sign
+// gives ~1e-5 rms on outputs of O(0.03..1) (measured against the float64 oracle in tests/test_spatial_gpu.py: <= 1e-4).
+// The FFT kernel above needed ~7 k vector instructions per frame for the same 28 x 64 numbers.
+//
+// One 4-wavefront workgroup keeps TWO frames in flight (wavefront = frame slot x pair tile); the phasors of a frame are
+// normalised and stored by the two wavefronts of its slot, the next two frames are requested into registers right after
+// the barrier and arrive while the products run.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kGmWaves = 4;
+constexpr int kGmThreads = kGmWaves * 64;
+constexpr int kGmUFloats = 61 * 8 * 16;                           // one frame: 61 bin groups x 8 channels x 8 bins x (re, im) = 31 232 B
+constexpr int kGmKSteps = 16;                                     // 512 bins / 32
+constexpr int kGmLagTiles = 3;                                    // lags 0..47 (0..32 used)
+constexpr int kGmTableFrags = 2 * kGmLagTiles * kGmKSteps;        // cos | sin: 96 fragments of 1 KB
+constexpr int kGmTableBytes = kGmTableFrags * 64 * 16;            // 98 304 B
+constexpr int kGmLdsBytes = kGmTableBytes + 2 * kGmUFloats * 4 + 16;   // 160 784 B (+ the two silent-bin flags)
+
+struct GccMfmaArgs {
+  const float* spec;     // [N][C][F][481] complex64
+  float* out;            // out[n*sN + pair*sC + j*sM + t*sT], j = 0..63 (lag j - 32)
+  long N, C, F;
+  long sN, sC, sM, sT;
+  const void* table;     // kGmTableBytes of fp16 B fragments (build_gcc_table)
+  long long* stamps;     // developer instrumentation (SELD_GCC_STAMPS): per-wavefront cycle sums of the loop phases, or null
+};
+
+// Value of element j (0..7) of lane `lane` of fragment (part, tile, kstep) of the table: T[n][k] with k = 32 kstep +
+// 8 (lane >> 4) + j the bin and n = 16 tile + (lane & 15) the lag (the A- and the B-operand fragment of the 16x16x32
+// MFMA hold the same (index, k) per lane, so the table serves either role; the kernel uses it as A).
+inline double gcc_table_value(int part, int tile, int kstep, int lane, int j) {
+  const int k = 32 * kstep + 8 * (lane >> 4) + j;
+  const int lag = 16 * tile + (lane & 15);
+  if (k > 480 || lag > 32) return 0.0;
+  const double w = (k == 0 || k == 480) ? 1.0 : 2.0;
+  const double ang = 2.0 * M_PI * static_cast<double>((static_cast<long>(k) * lag) % kNfft) / kNfft;
+  return part == 0 ? w * cos(ang) : -w * sin(ang);
+}
+
+// LDS layout of a frame's phasors: CHUNK q = 8 (bin / 8) + channel holds 8 bins of one channel as four float4 --
+// logical h = 0, 1: Re of bins 0..3, 4..7; h = 2, 3: Im -- (planar: the products below are then element-wise float4
+// arithmetic, i.e. packed instructions, and a pair of neighbouring bins converts to fp16 with one v_cvt_pk), the four
+// float4 ROTATED by rot(q) = (q >> 2) & 3: a wavefront's ds_read_b128 is serviced in four groups of 16 lanes that span
+// two of the four bin groups g = lane >> 4 and up to eight channels; with the rotation the 16-byte bank slot
+// (4 q + ((h + rot) & 3)) mod 16 is distinct for the 16 (channel, g parity) combinations of a group, so the reads are
+// conflict free without padding (channel-major rows gave 45 % of all LDS cycles as conflicts, SQ_LDS_BANK_CONFLICT).
+__device__ __forceinline__ int gm_chunk_slot(int q, int h) { return q * 16 + (((h + (q >> 2)) & 3) << 2); }   // float index
+
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+struct GmPhasors {            // 8 bins of the two channels of a pair: Re / Im x bins 0..3 / 4..7
+  f32x4 mr0, mr1, mi0, mi1, nr0, nr1, ni0, ni1;
+};
+
+__device__ __forceinline__ void gm_load(const float* u, const int (&om)[4], const int (&on)[4], int koff, GmPhasors& x) {
+  x.mr0 = *reinterpret_cast<const f32x4*>(u + om[0] + koff);
+  x.mr1 = *reinterpret_cast<const f32x4*>(u + om[1] + koff);
+  x.mi0 = *reinterpret_cast<const f32x4*>(u + om[2] + koff);
+  x.mi1 = *reinterpret_cast<const f32x4*>(u + om[3] + koff);
+  x.nr0 = *reinterpret_cast<const f32x4*>(u + on[0] + koff);
+  x.nr1 = *reinterpret_cast<const f32x4*>(u + on[1] + koff);
+  x.ni0 = *reinterpret_cast<const f32x4*>(u + on[2] + koff);
+  x.ni1 = *reinterpret_cast<const f32x4*>(u + on[3] + koff);
+}
+
+template <bool kHasZero>
+__device__ __forceinline__ void gm_fragments(const GmPhasors& x, half8& a_re, half8& a_im) {
+  const f32x4 mr0 = x.mr0, mr1 = x.mr1, mi0 = x.mi0, mi1 = x.mi1, nr0 = x.nr0, nr1 = x.nr1, ni0 = x.ni0, ni1 = x.ni1;
+  // conj(Um) Un = (mr nr + mi ni) + i (mr ni - mi nr)
+  f32x4 re0 = __builtin_elementwise_fma(mi0, ni0, mr0 * nr0), re1 = __builtin_elementwise_fma(mi1, ni1, mr1 * nr1);
+  f32x4 im0 = __builtin_elementwise_fma(-mi0, nr0, mr0 * ni0), im1 = __builtin_elementwise_fma(-mi1, nr1, mr1 * ni1);
+  if (kHasZero) {                                                   // a silent channel's phasor is 0: factor 1
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool z0 = (mr0[j] == 0.0f && mi0[j] == 0.0f) || (nr0[j] == 0.0f && ni0[j] == 0.0f);
+      const bool z1 = (mr1[j] == 0.0f && mi1[j] == 0.0f) || (nr1[j] == 0.0f && ni1[j] == 0.0f);
+      re0[j] = z0 ? 1.0f : re0[j];
+      im0[j] = z0 ? 0.0f : im0[j];
+      re1[j] = z1 ? 1.0f : re1[j];
+      im1[j] = z1 ? 0.0f : im1[j];
+    }
+  }
+  const half4 r0 = __builtin_convertvector(re0, half4), r1 = __builtin_convertvector(re1, half4);
+  const half4 i0 = __builtin_convertvector(im0, half4), i1 = __builtin_convertvector(im1, half4);
+  a_re = __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7);
+  a_im = __builtin_shufflevector(i0, i1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <bool kHasZero>
+__device__ __forceinline__ void gcc_mfma_frame(const GccMfmaArgs& a, const float* u, const half8* table, int lane, int mt,
+                                               int n_pairs, long n, long t) {
+  const int r = lane & 15, g = lane >> 4;
+  int p = 16 * mt + r;
+  if (p >= n_pairs) p = n_pairs - 1;                               // rows past the last pair repeat it (never stored)
+  int cm, cn;
+  pair_channels(p, static_cast<int>(a.C), cm, cn);
+  // float offsets of the four float4 of chunk (bin group g, channel) -- k-step ks adds 4 bin groups = 512 floats (the
+  // rotation does not change: 32 chunks further) -- and of bin group 60 (bins 480..487) for the last step's upper groups
+  int om[4], on[4], om_last[4], on_last[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    om[h] = gm_chunk_slot(8 * g + cm, h);
+    on[h] = gm_chunk_slot(8 * g + cn, h);
+    om_last[h] = g == 0 ? om[h] : gm_chunk_slot(cm, h);
+    on_last[h] = g == 0 ? on[h] : gm_chunk_slot(cn, h);
+  }
+  const half8* tab = table + lane;
+  f32x4 acc_c[kGmLagTiles], acc_s[kGmLagTiles];
+#pragma unroll
+  for (int tl = 0; tl < kGmLagTiles; ++tl)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc_c[tl][i] = acc_s[tl][i] = 0.0f;
+  // The table is the A operand (rows = lags), the phase factors the B operand (columns = pairs): a lane then holds FOUR
+  // CONSECUTIVE lags of one pair, D[row = lag 16 tile + 4 g + i][col = pair r], and stores them as one 16-byte vector.
+  // Everything a step reads from LDS -- the phasors AND the six table fragments -- is requested one step ahead (one
+  // wavefront per SIMD: nothing else hides the LDS latency; read at the point of use a step took ~600 cycles, most of
+  // them waiting for the fragments).  The last step reads bin group 60 for every lane: groups 61..63 do not exist and
+  // their table rows are zero.
+  struct TableFrags { half8 c[kGmLagTiles], s[kGmLagTiles]; };
+  auto table_load = [&](int ks, TableFrags& tf) {
+#pragma unroll
+    for (int tl = 0; tl < kGmLagTiles; ++tl) {
+      tf.c[tl] = tab[((0 * kGmLagTiles + tl) * kGmKSteps + ks) * 64];
+      tf.s[tl] = tab[((1 * kGmLagTiles + tl) * kGmKSteps + ks) * 64];
+    }
+  };
+  auto products = [&](const TableFrags& tf, const half8& b_re, const half8& b_im) {
+#pragma unroll
+    for (int tl = 0; tl < kGmLagTiles; ++tl) {
+      acc_c[tl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tf.c[tl], b_re, acc_c[tl], 0, 0, 0);
+      acc_s[tl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tf.s[tl], b_im, acc_s[tl], 0, 0, 0);
+    }
+  };
+  GmPhasors cur, nxt;
+  TableFrags tcur, tnxt;
+  gm_load(u, om, on, 0, cur);
+  table_load(0, tcur);
+#pragma unroll
+  for (int ks = 0; ks < kGmKSteps; ++ks) {                   // fully unrolled: every LDS offset is an immediate
+    if (ks + 1 < kGmKSteps - 1) gm_load(u, om, on, (ks + 1) * 512, nxt);
+    else if (ks + 1 == kGmKSteps - 1) gm_load(u, om_last, on_last, 60 * 8 * 16, nxt);
+    if (ks + 1 < kGmKSteps) table_load(ks + 1, tnxt);
+    __builtin_amdgcn_sched_barrier(0);                       // (left alone the scheduler sinks them to their use)
+    half8 b_re, b_im;
+    gm_fragments<kHasZero>(cur, b_re, b_im);
+    products(tcur, b_re, b_im);
+    cur = nxt;
+    tcur = tnxt;
+  }
+  // cc[+l] = (C[l] + S[l]) / 960 at index 32 + l (l = 0..31),  cc[-l] = (C[l] - S[l]) / 960 at index 32 - l (l = 1..32);
+  // the lag stride of the output is 1 (the host checks): 16-byte stores, the second set at a 4-byte aligned address.
+  const float sc = 1.0f / 960.0f;
+  const int pair = 16 * mt + r;
+  if (pair < n_pairs) {
+    float* op = a.out + n * a.sN + pair * a.sC + t * a.sT;
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) {
+      const int l0 = 16 * tl + 4 * g;
+      const f32x4 plus = (acc_c[tl] + acc_s[tl]) * sc;
+      const f32x4 minus = (acc_c[tl] - acc_s[tl]) * sc;            // at l0 = 0 its first value is cc[0] again (S[0] = 0)
+      *reinterpret_cast<f32x4*>(op + 32 + l0) = plus;
+      struct __attribute__((packed, aligned(4))) Unaligned4 { float v[4]; };
+      Unaligned4 rev = {{minus[3], minus[2], minus[1], minus[0]}};
+      *reinterpret_cast<Unaligned4*>(op + 29 - l0) = rev;
+    }
+    if (g == 0) op[0] = (acc_c[2][0] - acc_s[2][0]) * sc;          // lag -32
+  }
+}
+
+// Workgroup barrier that orders LDS only.  __syncthreads() is a workgroup-scope release / acquire fence as well: it
+// waits for EVERY outstanding global access of the wavefront (s_waitcnt vmcnt(0)) -- here the output stores of the frame
+// just finished and the requests for the next one, i.e. a full HBM round trip per barrier with nothing to show for it:
+// the waves only exchange data through LDS.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int kGmBinsPerLane = 4;                                  // bins tt, tt + 128, tt + 256, tt + 384 (< 481) of every channel
+
+__global__ __launch_bounds__(kGmThreads, 1) void gcc_mfma_kernel(GccMfmaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int slot = __builtin_amdgcn_readfirstlane(wave >> 1);      // frame slot and pair tile: wavefront-uniform, kept
+  const int mt = __builtin_amdgcn_readfirstlane(wave & 1);         // scalar (frame / row arithmetic on the scalar unit)
+  half8* table = reinterpret_cast<half8*>(smem_raw);
+  float* u = reinterpret_cast<float*>(smem_raw + kGmTableBytes) + slot * kGmUFloats;
+  {                                                                // the constant table, once per workgroup
+    const uint4* src = static_cast<const uint4*>(a.table);
+    uint4* dst = reinterpret_cast<uint4*>(smem_raw);
+    for (int i = tid; i < kGmTableBytes / 16; i += kGmThreads) dst[i] = src[i];
+    float* uz = reinterpret_cast<float*>(smem_raw + kGmTableBytes);
+    for (int i = tid; i < 2 * kGmUFloats; i += kGmThreads) uz[i] = 0.0f;      // bins 481..487 and unused channels stay zero
+  }
+  const int n_pairs = static_cast<int>(a.C * (a.C - 1) / 2);
+  const int n_tiles = (n_pairs + 15) / 16;
+  const int n_ch = static_cast<int>(a.C);
+  const long total = a.N * a.F;
+  const int ch_stride_i = static_cast<int>(a.F * kBins);
+  const int tt = tid & 127;                                        // index within the slot's two wavefronts
+  const float2* spec2 = reinterpret_cast<const float2*>(a.spec);
+  auto frame_base = [&](long f) {
+    const long n = f / a.F;
+    return spec2 + (n * a.C * a.F + (f - n * a.F)) * kBins;
+  };
+  // Lane tt stages bins tt + 128 i (i = 0..3; the last only for tt < 97) of every channel.  Where a bin goes in its chunk
+  // (gm_chunk_slot) is loop invariant: channel c adds 16 floats -- an immediate -- and channels 4..7 rotate one float4
+  // further than 0..3, so four offsets per bin (Re / Im x channel half) are all the address arithmetic of the frame loop.
+  int dst[kGmBinsPerLane][4];
+  unsigned src_bin[kGmBinsPerLane];
+#pragma unroll
+  for (int i = 0; i < kGmBinsPerLane; ++i) {
+    const int bin = tt + 128 * i < kBins ? tt + 128 * i : kBins - 1;      // lanes past the last bin repeat it (not stored)
+    const int q0 = 8 * (bin >> 3), j = bin & 7;
+    dst[i][0] = gm_chunk_slot(q0, j >> 2) + (j & 3);                       // Re, channels 0..3 (+ 16 c)
+    dst[i][1] = gm_chunk_slot(q0 + 4, j >> 2) + (j & 3) - 64;              // Re, channels 4..7 (+ 16 c)
+    dst[i][2] = gm_chunk_slot(q0, 2 + (j >> 2)) + (j & 3);                 // Im
+    dst[i][3] = gm_chunk_slot(q0 + 4, 2 + (j >> 2)) + (j & 3) - 64;
+    src_bin[i] = static_cast<unsigned>(bin);
+  }
+  const bool last_bin_valid = tt + 128 * (kGmBinsPerLane - 1) < kBins;
+  auto request = [&](const float2* src, float2 (&pre)[8][kGmBinsPerLane]) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const unsigned coff = static_cast<unsigned>(c < n_ch ? c : 0) * static_cast<unsigned>(ch_stride_i);   // uniform
+#pragma unroll
+      for (int i = 0; i < kGmBinsPerLane; ++i) pre[c][i] = src[coff + src_bin[i]];
+    }
+  };
+  const long stride = 2L * gridDim.x;
+  long f = 2L * blockIdx.x + slot;                                 // this slot's frame
+  // (A second register set of requests, issued two iterations ahead, was tried: no gain -- the loop is not waiting for HBM
+  // -- and its 64 registers pushed the products' LDS reads back to their use.)
+  float2 pre_a[8][kGmBinsPerLane];
+  auto clamp_frame = [&](long fr) { return fr < total ? fr : (f < total ? f : total - 1); };
+  request(frame_base(clamp_frame(f)), pre_a);
+  int* flags = reinterpret_cast<int*>(smem_raw + kGmTableBytes + 2 * kGmUFloats * 4);   // silent-bin flag per iteration parity
+  if (tid < 2) flags[tid] = 0;
+  __syncthreads();                                                 // the table and the zeroed buffers are in place
+  int parity = 0;
+  long long ph[5] = {0, 0, 0, 0, 0};                              // barrier A, staging, request + barrier B, products, (count)
+  auto iteration = [&](float2 (&pre)[8][kGmBinsPerLane]) {
+    long long t0 = a.stamps ? static_cast<long long>(__builtin_readcyclecounter()) : 0;
+    lds_barrier();                                                 // the previous frames' readers are done
+    if (a.stamps) { const long long t1 = static_cast<long long>(__builtin_readcyclecounter()); ph[0] += t1 - t0; t0 = t1; }
+    if (tid == 0) flags[parity ^ 1] = 0;                           // (read last in the previous iteration)
+    int zero = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if (c < n_ch) {                                              // uniform
+        float nx[kGmBinsPerLane], ny[kGmBinsPerLane];
+#pragma unroll
+        for (int i = 0; i < kGmBinsPerLane; ++i) {
+          const float2 x = pre[c][i];
+          const float mag2 = x.x * x.x + x.y * x.y;
+          const bool sounding = mag2 > kGccSilencePower;
+          const float inv = sounding ? rsqrtf(mag2) : 0.0f;
+          zero |= sounding ? 0 : 1;                                // (a repeated last bin flags what its owner flags)
+          nx[i] = x.x * inv;
+          ny[i] = x.y * inv;
+        }
+        float* uc = u + 16 * (c & 3) + 64 * (c >> 2);              // channel c: + 16 c floats
+#pragma unroll
+        for (int i = 0; i < kGmBinsPerLane - 1; ++i) {
+          uc[dst[i][c >> 2]] = nx[i];
+          uc[dst[i][2 + (c >> 2)]] = ny[i];
+        }
+        if (last_bin_valid) {
+          uc[dst[kGmBinsPerLane - 1][c >> 2]] = nx[kGmBinsPerLane - 1];
+          uc[dst[kGmBinsPerLane - 1][2 + (c >> 2)]] = ny[kGmBinsPerLane - 1];
+        }
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(zero != 0) != 0 && lane == 0) flags[parity] = 1;
+    __builtin_amdgcn_sched_barrier(0);
+    if (a.stamps) { const long long t1 = static_cast<long long>(__builtin_readcyclecounter()); ph[1] += t1 - t0; t0 = t1; }
+    request(frame_base(clamp_frame(f + stride)), pre);             // the slot's next frame: in flight across the products
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+    const int has_zero = flags[parity];
+    if (a.stamps) { const long long t1 = static_cast<long long>(__builtin_readcyclecounter()); ph[2] += t1 - t0; t0 = t1; }
+    if (f < total && mt < n_tiles) {
+      const long n = f / a.F;
+      const long t = f - n * a.F;
+      if (has_zero) gcc_mfma_frame<true>(a, u, table, lane, mt, n_pairs, n, t);
+      else gcc_mfma_frame<false>(a, u, table, lane, mt, n_pairs, n, t);
+    }
+    if (a.stamps) { const long long t1 = static_cast<long long>(__builtin_readcyclecounter()); ph[3] += t1 - t0; ph[4] += 1; }
+    f += stride;
+    parity ^= 1;
+  };
+  for (long f0 = 2L * blockIdx.x; f0 < total; f0 += stride) iteration(pre_a);   // uniform trip count for the workgroup
+  if (a.stamps && lane == 0 && blockIdx.x < 64) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) a.stamps[(blockIdx.x * kGmWaves + wave) * 5 + k] = ph[k];
+  }
+}
+
+
 }  // namespace seld
 
 extern "C" {
@@ -319,6 +634,40 @@ int seld_foa_intensity(const float* spec_complex, int64_t N, int64_t F, float* o
   return kOk;
 }
 
+// fp32 -> IEEE binary16 bits, round to nearest even (host side of the table build; |v| <= 2, no overflow handling needed)
+static unsigned short half_bits(float v) {
+  unsigned u;
+  memcpy(&u, &v, 4);
+  const unsigned sign = (u >> 16) & 0x8000u;
+  const int exp = static_cast<int>((u >> 23) & 0xff) - 127 + 15;
+  unsigned man = u & 0x7fffffu;
+  if (exp <= 0) {                                   // subnormal half (or zero)
+    if (exp < -10) return static_cast<unsigned short>(sign);
+    man |= 0x800000u;
+    const int shift = 14 - exp;                     // 24-bit significand -> 10 bits at exponent 0
+    const unsigned half = man >> shift, rem = man & ((1u << shift) - 1), mid = 1u << (shift - 1);
+    return static_cast<unsigned short>(sign | (half + ((rem > mid || (rem == mid && (half & 1))) ? 1 : 0)));
+  }
+  const unsigned half = (static_cast<unsigned>(exp) << 10) | (man >> 13), rem = man & 0x1fffu;
+  return static_cast<unsigned short>(sign | (half + ((rem > 0x1000u || (rem == 0x1000u && (half & 1))) ? 1 : 0)));
+}
+
+static int ensure_gcc_table(seld::DeviceState* st) {
+  using namespace seld;
+  if (st->gcc_table) return kOk;
+  std::vector<unsigned short> host(kGmTableBytes / 2);
+  for (int part = 0; part < 2; ++part)
+    for (int tile = 0; tile < kGmLagTiles; ++tile)
+      for (int ks = 0; ks < kGmKSteps; ++ks)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j)
+            host[((((part * kGmLagTiles + tile) * kGmKSteps + ks) * 64) + lane) * 8 + j] =
+                half_bits(static_cast<float>(gcc_table_value(part, tile, ks, lane, j)));
+  SELD_HIP_TRY(hipMalloc(&st->gcc_table, kGmTableBytes));
+  SELD_HIP_TRY(hipMemcpy(st->gcc_table, host.data(), kGmTableBytes, hipMemcpyHostToDevice));
+  return kOk;
+}
+
 int seld_gcc_phat(const float* spec_complex, int64_t N, int64_t C, int64_t F, float* out, int64_t sN, int64_t sC,
                   int64_t sM, int64_t sT, void* stream_) {
   using namespace seld;
@@ -327,6 +676,44 @@ int seld_gcc_phat(const float* spec_complex, int64_t N, int64_t C, int64_t F, fl
   if (!spec_complex || !out) return fail(kErrInvalidArgument, "seld_gcc_phat: null pointer");
   if (N <= 0 || F <= 0) return fail(kErrInvalidArgument, "seld_gcc_phat: N and F must be positive");
   if (C < 2 || C > 8) return fail(kErrUnsupported, "seld_gcc_phat: 2..8 channels");
+  if (C * F * kBins >= (1L << 31)) return fail(kErrUnsupported, "seld_gcc_phat: a clip's spectra exceed 2^31 complex values");
+  // SELD_GCC=fft selects the round-2a kernel (14 packed pruned inverse FFTs per frame on the vector units): developer A/B
+  static const bool use_fft = [] {
+    const char* v = getenv("SELD_GCC");
+    return v && v[0] == 'f';
+  }();
+  // the matrix-core kernel stores four consecutive lags as one vector: unit lag stride, 16-byte aligned rows
+  const bool vector_rows = sM == 1 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && sN % 4 == 0 && sC % 4 == 0 && sT % 4 == 0;
+  if (!use_fft && vector_rows) {
+    const int rc = ensure_gcc_table(st);
+    if (rc != kOk) return rc;
+    GccMfmaArgs a{spec_complex, out, N, C, F, sN, sC, sM, sT, st->gcc_table, nullptr};
+    static const bool want_stamps = getenv("SELD_GCC_STAMPS") != nullptr;      // developer instrumentation
+    if (want_stamps) SELD_HIP_TRY(hipMalloc(&a.stamps, 64 * kGmWaves * 5 * sizeof(long long)));
+    long blocks = (N * F + 1) / 2;
+    if (blocks > st->num_cus) blocks = st->num_cus;         // persistent: the 96 KB table is staged once per workgroup
+    if (need_lds(st, kAttrGccMfma)) {
+      SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gcc_mfma_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kGmLdsBytes));
+      lds_attr_set(st, kAttrGccMfma);
+    }
+    hipLaunchKernelGGL(gcc_mfma_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kGmThreads), kGmLdsBytes,
+                       static_cast<hipStream_t>(stream_), a);
+    SELD_HIP_TRY(hipGetLastError());
+    if (want_stamps) {
+      std::vector<long long> h(64 * kGmWaves * 5);
+      SELD_HIP_TRY(hipMemcpy(h.data(), a.stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      double sum[5] = {0, 0, 0, 0, 0};
+      const long nb = blocks < 64 ? blocks : 64;
+      for (long i = 0; i < nb * kGmWaves; ++i)
+        for (int k = 0; k < 5; ++k) sum[k] += static_cast<double>(h[i * 5 + k]);
+      fprintf(stderr, "gcc_mfma stamps (cycles per iteration and wavefront): barrier A %.0f, staging %.0f, request + barrier B %.0f, "
+              "products + stores %.0f (%.0f iterations)\n", sum[0] / sum[4], sum[1] / sum[4], sum[2] / sum[4], sum[3] / sum[4],
+              sum[4] / (nb * kGmWaves));
+      (void)hipFree(a.stamps);
+    }
+    return kOk;
+  }
   GccArgs a{spec_complex, out, N, C, F, sN, sC, sM, sT, st->tables()};
   long blocks = N * F;
   const long cap = static_cast<long>(st->num_cus) * 4;
