@@ -287,8 +287,7 @@ __global__ __launch_bounds__(kGccThreads, 2) void gcc_phat_kernel(GccArgs a) {
       if (e < n_elems) u[e] = cf_make(pre[j].x * inv, pre[j].y * inv);
     }
     const int has_zero = __syncthreads_or(zero);
-    // The next frame of this workgroup, requested AFTER the barrier (its fence waits for every outstanding load: issued
-    // before it the loads would be waited for on the spot) and pinned ahead of the transforms that cover their latency.
+    // The next frame of this workgroup, requested here and pinned ahead of the transforms that cover its latency.
     // Clamped, not conditional: the last requests re-read this frame.
     __builtin_amdgcn_sched_barrier(0);
     {
@@ -485,10 +484,11 @@ __device__ __forceinline__ void gcc_mfma_frame(const GccMfmaArgs& a, const float
   }
 }
 
-// Workgroup barrier that orders LDS only.  __syncthreads() is a workgroup-scope release / acquire fence as well: it
-// waits for EVERY outstanding global access of the wavefront (s_waitcnt vmcnt(0)) -- here the output stores of the frame
-// just finished and the requests for the next one, i.e. a full HBM round trip per barrier with nothing to show for it:
-// the waves only exchange data through LDS.
+// Workgroup barrier for data exchanged through LDS: wait for this wavefront's LDS operations, then s_barrier -- what hipcc
+// emits for __syncthreads() on this target (checked in the ISA: no vmcnt wait, the requests for the next frame stay in
+// flight across it).  Spelled out because the silent-bin flag below replaces __syncthreads_or, which costs two barriers
+// and an LDS reduction per call: here it is one LDS word per iteration parity, written by the wavefronts that saw a
+// silent bin and read after the barrier that the staging needs anyway.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr int kGmBinsPerLane = 4;                                  // bins tt, tt + 128, tt + 256, tt + 384 (< 481) of every channel
