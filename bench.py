@@ -195,7 +195,7 @@ class HotPath:
             e0.record()
         if self.features == "logmel":
             nat.logmel(self.pcm, layout="tcf", out=self.spec_full)
-        else:                               # log-mel + STFT + intensity vectors / GCC-PHAT (csrc/spatial.hip)
+        else:                               # log-mel + spectra in one pass, then intensity vectors / GCC-PHAT (csrc/spatial.hip)
             self.spec_full = nat.spatial_features(self.pcm, self.features)
         if timed:
             e1.record()
@@ -488,7 +488,7 @@ def main():
                        "parallelism": f"dp{world}", "windows_per_s": clips * 60 / elapsed,
                        "final_loss": float(loss.item())},
             "roofline": {"kernel": "seld::logmel_main_kernel<float> + logmel_edge_kernel<float> (fused STFT+mel+dB)"
-                         if args.features == "logmel" else f"feature phase: log-mel + STFT + {args.features[7:]} kernels",
+                         if args.features == "logmel" else f"feature phase: seld::logmel_main_kernel<float, true> (log-mel + spectra) + {'seld::gcc_mfma_kernel' if args.features == 'logmel_gcc' else 'seld::foa_iv_kernel'}",
                          "bound": "hbm",
                          "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS,
