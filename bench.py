@@ -84,6 +84,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-rooflines", action="store_true",
+                    help="skip the post-timing micro-benchmarks of the hand-written kernels (profiled runs: the kernel "
+                         "trace then holds the steps only)")
     ap.add_argument("--model", default="crnn", choices=["crnn", "conformer", "resnet_conformer"])
     ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (parity runs)")
     ap.add_argument("--features", default="logmel", choices=["logmel", "logmel_iv", "logmel_gcc"],
@@ -515,7 +518,7 @@ def main():
         if hasattr(hot.optimizer, "fused_casts"):
             line["config"]["master_weights"] = {"one_launch_gradient_casts": hot.optimizer.fused_casts,
                                                 "per_tensor_fallbacks": hot.optimizer.fallback_casts}
-        if world == 1:
+        if world == 1 and not args.no_kernel_rooflines:
             line["kernels"] = kernel_rooflines(device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
