@@ -124,7 +124,13 @@ def launch_ranks(args) -> int:
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    # stdout carries the ONE JSON line of rank 0 and nothing else: whatever the ranks' libraries print there (gloo's
+    # connection banner in the rehearsal mode) is passed on to stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+        (sys.stdout if line.startswith("{") else sys.stderr).flush()
+    return proc.wait()
 
 
 def synth_metadata(clip_idx: int, meta_frames: int = 600) -> np.ndarray:
