@@ -42,6 +42,20 @@ if src_pmc.exists():
         shutil.copy(p, out / f"{tag}_pmc_logmel_{p.name}")
 if bench_json and bench_json.exists():
     shutil.copy(bench_json, out / f"{tag}_bench.json")
+# the other workloads of tools/round_artifacts.sh part b: bench lines and the timed-region statistics of their profiled runs
+for extra in ("eager", "conformer", "resnet_conformer", "mic8_gcc", "rehearsal_2ranks"):
+    src = ROOT / "gpurun_out" / f"bench_{tag}_{extra}.json"
+    if src.exists():
+        lines = [l for l in open(src) if l.startswith("{")]
+        (out / f"{tag}_bench_{extra}.json").write_text("".join(lines))
+    prof = ROOT / "gpurun_out" / f"prof_{tag}_{extra}"
+    if (prof / "bench_timed_region_stats.csv").exists():
+        shutil.copy(prof / "bench_timed_region_stats.csv", out / f"{tag}_{extra}_timed_region_stats.csv")
+        if (prof / "timed_region.log").exists():
+            shutil.copy(prof / "timed_region.log", out / f"{tag}_{extra}_timed_region.txt")
+        if (prof / "iteration_timeline.txt").exists():
+            (out / f"{tag}_{extra}_iteration_timeline.txt").write_text(
+                "".join(l[:170].rstrip() + "\n" for l in open(prof / "iteration_timeline.txt")))
 
 # traffic of the log-mel main kernel from the PMC passes (MI355X_MICROARCH.md, HBM section: FETCH_SIZE reads
 # half of a coalesced stream on gfx950 -> x2; WRITE_SIZE exact; both in KiB)

@@ -5,4 +5,4 @@
 TAG=${1:-r02_iter}
 MODEL=${2:-crnn}
 cd $GRAFT_REPO_ROOT
-SELD_GRAPH_STEP=0 bash tools/pmc_kernel.sh $TAG "conv|Cijk|igemm|gru_|attn|bwd_kernel|gemm|Gemm" python3 $GRAFT_REPO_ROOT/tools/iter_profile.py 4 $MODEL
+PMC_KEEP_ROWS=600 SELD_GRAPH_STEP=0 bash tools/pmc_kernel.sh $TAG "conv|Cijk|igemm|gru_|attn|bwd_kernel|gemm|Gemm" python3 $GRAFT_REPO_ROOT/tools/iter_profile.py 4 $MODEL

@@ -16,6 +16,6 @@ for CTRS in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST
   rm -rf $RAW
   rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $RAW -o p -- "$@" > $OUT/pass$i.stdout 2>&1 || { echo "pass $i failed"; tail -5 $OUT/pass$i.stdout; continue; }
   F=$(find $RAW -name "*counter_collection.csv" | head -1)
-  if [ -n "$F" ]; then head -1 $F > $OUT/pass$i.csv; grep -E "$FILTER" $F | tail -64 >> $OUT/pass$i.csv; fi
+  if [ -n "$F" ]; then head -1 $F > $OUT/pass$i.csv; grep -E "$FILTER" $F | tail -${PMC_KEEP_ROWS:-64} >> $OUT/pass$i.csv; fi
 done
 ls -la $OUT
