@@ -678,10 +678,8 @@ int seld_gcc_phat(const float* spec_complex, int64_t N, int64_t C, int64_t F, fl
   if (C < 2 || C > 8) return fail(kErrUnsupported, "seld_gcc_phat: 2..8 channels");
   if (C * F * kBins >= (1L << 31)) return fail(kErrUnsupported, "seld_gcc_phat: a clip's spectra exceed 2^31 complex values");
   // SELD_GCC=fft selects the round-2a kernel (14 packed pruned inverse FFTs per frame on the vector units): developer A/B
-  static const bool use_fft = [] {
-    const char* v = getenv("SELD_GCC");
-    return v && v[0] == 'f';
-  }();
+  const char* which = getenv("SELD_GCC");                          // read per call: the tests run both kernels in one process
+  const bool use_fft = which && which[0] == 'f';
   // the matrix-core kernel stores four consecutive lags as one vector: unit lag stride, 16-byte aligned rows
   const bool vector_rows = sM == 1 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && sN % 4 == 0 && sC % 4 == 0 && sT % 4 == 0;
   if (!use_fft && vector_rows) {

@@ -41,9 +41,13 @@ def test_foa_intensity_vectors(gpu_device):
     assert np.abs(ref[0]).max() > 0.1                                     # the planted correlation shows up
 
 
+@pytest.mark.parametrize("kernel", ["mfma", "fft"])
 @pytest.mark.parametrize("channels", [8, 4, 2])
-def test_gcc_phat(gpu_device, channels):
+def test_gcc_phat(gpu_device, channels, kernel, monkeypatch):
+    """Both GCC-PHAT kernels (csrc/spatial.hip): the matrix-core one (default) and the FFT-based one that serves outputs
+    whose lag stride is not 1 (SELD_GCC=fft selects it for any layout)."""
     import seld_native
+    monkeypatch.setenv("SELD_GCC", kernel)
     pcm = ofeat.synth_pcm(6, channels, 12000 + 17, "noise")
     pcm[1, 7:] = pcm[0, :-7]                                              # channel 1 = channel 0 delayed by 7 samples
     feat = seld_native.spatial_features(pcm.to(gpu_device), "logmel_gcc").cpu()
@@ -69,11 +73,13 @@ def test_batched_spatial_features(gpu_device):
         assert torch.equal(gcc[i], seld_native.spatial_features(pcm[i], "logmel_gcc"))
 
 
-def test_gcc_phat_with_a_silent_channel(gpu_device):
+@pytest.mark.parametrize("kernel", ["mfma", "fft"])
+def test_gcc_phat_with_a_silent_channel(gpu_device, kernel, monkeypatch):
     """X = 0 must give R / |R| = 1 (np.exp(1j * np.angle(0))): pairs with the dead microphone are a unit pulse at lag 0,
     the other pairs are untouched.  (The kernel stores a zero phasor for such a channel and switches, per frame, to the
     variant that turns zero products into 1 -- csrc/spatial.hip.)"""
     import seld_native
+    monkeypatch.setenv("SELD_GCC", kernel)
     pcm = ofeat.synth_pcm(11, 4, 9600 + 5, "noise")
     pcm[2] = 0.0
     pcm[:, 4800:6000] = 0.0                                               # and a stretch of digital silence in all of them
