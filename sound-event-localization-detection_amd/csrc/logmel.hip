@@ -6,7 +6,7 @@ namespace seld {
 
 constexpr int kMainWaves = 8;    // main kernel: 512 threads, two wavefronts per SIMD (<= 256 VGPRs, no spills)
 constexpr int kEdgeWaves = 4;    // edge kernel: 256 threads
-constexpr int kMainLdsBytes = (kTabFloats + kMainWaves * kLdsFloatsPerWave) * 4;   // 160768 B: one workgroup per CU
+constexpr int kMainLdsBytes = (kTabFloats + kMainWaves * kLdsFloatsPerWave) * 4;   // 152576 B: one workgroup per CU
 constexpr int kEdgeLdsBytes = (kTabFloats + kEdgeWaves * kLdsFloatsPerWave) * 4;
 
 struct LogmelArgs {
@@ -31,6 +31,11 @@ __device__ __forceinline__ float* out_pointer(const LogmelArgs& a, long row, lon
 
 __device__ __forceinline__ void fill_tables(const LogmelArgs& a, float* tab, int tid, int nthreads) {
   for (int e = tid; e < kTabFloats; e += nthreads) tab[e] = table_value(a.tab, e);
+}
+
+// Value of `v` in the lane below (0 in lane 0): DPP wave_shr:1 -- the B_j hand-off of the mel phase without LDS.
+__device__ __forceinline__ float lane_below(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
 }
 
 #define SELD_WAVE_SYNC()                                   \
@@ -71,9 +76,10 @@ __device__ __forceinline__ void edge_iteration(const LogmelArgs& a, long e, int 
   SELD_WAVE_SYNC();
   LaneAcc acc;
   phase_d_accumulate(lane, lds, tab, seg, acc);
-  SELD_WAVE_SYNC();
-  float db[kFramesPerIter];
-  phase_d_finish(lane, lds, acc, db);
+  float below[kFramesPerIter], db[kFramesPerIter];
+#pragma unroll
+  for (int f = 0; f < kFramesPerIter; ++f) below[f] = lane_below(acc.ab[f].y);
+  phase_d_finish(acc, below, db);
   float* outp = out_pointer(a, row, itr, lane);
 #pragma unroll
   for (int f = 0; f < kFramesPerIter; ++f)
@@ -166,9 +172,10 @@ __global__ __launch_bounds__(kMainWaves * 64, 2) void logmel_main_kernel(LogmelA
     SELD_WAVE_SYNC();
     LaneAcc acc;
     phase_d_accumulate(lane, lds, tab, seg, acc);
-    SELD_WAVE_SYNC();
-    float db[kFramesPerIter];
-    phase_d_finish(lane, lds, acc, db);
+    float below[kFramesPerIter], db[kFramesPerIter];
+#pragma unroll
+    for (int f = 0; f < kFramesPerIter; ++f) below[f] = lane_below(acc.ab[f].y);
+    phase_d_finish(acc, below, db);
 #pragma unroll
     for (int f = 0; f < kFramesPerIter; ++f) outp[f * a.sT] = db[f];
     SELD_WAVE_SYNC();

@@ -51,8 +51,7 @@ constexpr int kZmFloatsPerHalf = kBins * 2;              // 962: mirror buffer (
 constexpr int kPOff = 0;
 constexpr int kPPitch = 800;
 constexpr int kPDummy = kPPitch - 1;                     // where bins nobody accumulates are written (never read with weight != 0)
-constexpr int kBsOff = kEFloats;                         // 3968: B_j hand-off, [4][64]
-constexpr int kLdsFloatsPerWave = kEFloats + 4 * 64;     // 4224 floats = 16896 B
+constexpr int kLdsFloatsPerWave = kEFloats;              // 3968 floats = 15872 B
 constexpr int kMelMaxCnt = 24;          // max bins owned by one lane (checked when tables are built)
 constexpr int kFramesPerIter = 4;
 constexpr float kAmin = 1e-10f;
@@ -302,9 +301,6 @@ SELD_HD void phase_d_accumulate(int lane, float* lds, const float* tab, int seg,
       for (int s = 0; s < kFramesPerIter; ++s)
         acc.ab[s] = cf_fma(w[k], cf_make(q[s].p[k], q[s].p[k]), acc.ab[s]);
   }
-  float* bs = lds + kBsOff + lane;
-#pragma unroll
-  for (int s = 0; s < kFramesPerIter; ++s) bs[s * 64] = acc.ab[s].y;
 }
 
 // 10*log10(max(p, 1e-10)) as 10*log10(2) * log2(p): one v_log_f32 (<= 1 ulp of log2, i.e. < 1e-5 dB) instead
@@ -318,12 +314,11 @@ SELD_HD float power_to_db(float p) {
   return p > kAmin ? 3.0102999566398120f * l2 : -100.0f;
 }
 
-SELD_HD void phase_d_finish(int lane, const float* lds, const LaneAcc& acc, float (&db)[kFramesPerIter]) {
+// mel[j] = A_j + B_{j-1}: `below[s]` is lane j - 1's B sum of frame slot s (0 for lane 0) -- one cross-lane move on the
+// GPU (lane_below in logmel.hip: a DPP wave shift, no LDS round trip), the neighbour's accumulator in the lane emulator.
+SELD_HD void phase_d_finish(const LaneAcc& acc, const float (&below)[kFramesPerIter], float (&db)[kFramesPerIter]) {
 #pragma unroll
-  for (int s = 0; s < kFramesPerIter; ++s) {
-    const float below = lane > 0 ? (lds + kBsOff + lane - 1)[s * 64] : 0.0f;
-    db[s] = power_to_db(acc.ab[s].x + below);
-  }
+  for (int s = 0; s < kFramesPerIter; ++s) db[s] = power_to_db(acc.ab[s].x + below[s]);
 }
 
 }  // namespace seld

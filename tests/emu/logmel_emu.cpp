@@ -84,7 +84,9 @@ int run(const T* pcm, int64_t N, int64_t C, int64_t L, float* out, int layout, c
         phase_d_accumulate(lane, lds.data(), tab_lds.data(), t.pos[lane], acc[lane]);
       for (int lane = 0; lane < 64; ++lane) {
         float db[kFramesPerIter];
-        phase_d_finish(lane, lds.data(), acc[lane], db);
+        float below[kFramesPerIter];
+        for (int s = 0; s < kFramesPerIter; ++s) below[s] = lane > 0 ? acc[lane - 1].ab[s].y : 0.0f;
+        phase_d_finish(acc[lane], below, db);
         float* outp = out + n * sN + c * sC + lane * sM;
         for (int s = 0; s < kFramesPerIter; ++s)
           if (tf + s < F) outp[(tf + s) * sT] = db[s];
