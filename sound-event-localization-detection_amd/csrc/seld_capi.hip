@@ -90,6 +90,8 @@ int seld_init(int device) {
   default_mel_filterbank(fb);
   const int rc = upload_mel(st, fb);
   if (rc != kOk) return rc;
+  const int rc_gcc = build_gcc_table(&st);
+  if (rc_gcc != kOk) return rc_gcc;
   SELD_HIP_TRY(hipStreamCreateWithFlags(&st.side_stream, hipStreamNonBlocking));
   SELD_HIP_TRY(hipEventCreateWithFlags(&st.fork_event, hipEventDisableTiming));
   SELD_HIP_TRY(hipEventCreateWithFlags(&st.join_event, hipEventDisableTiming));

@@ -71,4 +71,7 @@ inline void lds_attr_set(DeviceState* st, unsigned bit) { st->lds_attr_done |= b
 // has not been called for it.
 DeviceState* current_state();
 
+// spatial.hip: the constant fp16 cosine / sine table of the matrix-core GCC-PHAT kernel (96 KB, built by seld_init)
+int build_gcc_table(DeviceState* st);
+
 }  // namespace seld

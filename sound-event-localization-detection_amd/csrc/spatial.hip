@@ -613,6 +613,40 @@ __global__ __launch_bounds__(kGmThreads, 1) void gcc_mfma_kernel(GccMfmaArgs a) 
 }
 
 
+// fp32 -> IEEE binary16 bits, round to nearest even (host side of the table build; |v| <= 2, no overflow handling needed)
+static unsigned short half_bits(float v) {
+  unsigned u;
+  memcpy(&u, &v, 4);
+  const unsigned sign = (u >> 16) & 0x8000u;
+  const int exp = static_cast<int>((u >> 23) & 0xff) - 127 + 15;
+  unsigned man = u & 0x7fffffu;
+  if (exp <= 0) {                                   // subnormal half (or zero)
+    if (exp < -10) return static_cast<unsigned short>(sign);
+    man |= 0x800000u;
+    const int shift = 14 - exp;                     // 24-bit significand -> 10 bits at exponent 0
+    const unsigned half = man >> shift, rem = man & ((1u << shift) - 1), mid = 1u << (shift - 1);
+    return static_cast<unsigned short>(sign | (half + ((rem > mid || (rem == mid && (half & 1))) ? 1 : 0)));
+  }
+  const unsigned half = (static_cast<unsigned>(exp) << 10) | (man >> 13), rem = man & 0x1fffu;
+  return static_cast<unsigned short>(sign | (half + ((rem > 0x1000u || (rem == 0x1000u && (half & 1))) ? 1 : 0)));
+}
+
+// Called once per device by seld_init (seld_capi.hip): the library allocates nothing at call time.
+int build_gcc_table(DeviceState* st) {
+  if (st->gcc_table) return kOk;
+  std::vector<unsigned short> host(kGmTableBytes / 2);
+  for (int part = 0; part < 2; ++part)
+    for (int tile = 0; tile < kGmLagTiles; ++tile)
+      for (int ks = 0; ks < kGmKSteps; ++ks)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j)
+            host[((((part * kGmLagTiles + tile) * kGmKSteps + ks) * 64) + lane) * 8 + j] =
+                half_bits(static_cast<float>(gcc_table_value(part, tile, ks, lane, j)));
+  SELD_HIP_TRY(hipMalloc(&st->gcc_table, kGmTableBytes));
+  SELD_HIP_TRY(hipMemcpy(st->gcc_table, host.data(), kGmTableBytes, hipMemcpyHostToDevice));
+  return kOk;
+}
+
 }  // namespace seld
 
 extern "C" {
@@ -634,40 +668,6 @@ int seld_foa_intensity(const float* spec_complex, int64_t N, int64_t F, float* o
   return kOk;
 }
 
-// fp32 -> IEEE binary16 bits, round to nearest even (host side of the table build; |v| <= 2, no overflow handling needed)
-static unsigned short half_bits(float v) {
-  unsigned u;
-  memcpy(&u, &v, 4);
-  const unsigned sign = (u >> 16) & 0x8000u;
-  const int exp = static_cast<int>((u >> 23) & 0xff) - 127 + 15;
-  unsigned man = u & 0x7fffffu;
-  if (exp <= 0) {                                   // subnormal half (or zero)
-    if (exp < -10) return static_cast<unsigned short>(sign);
-    man |= 0x800000u;
-    const int shift = 14 - exp;                     // 24-bit significand -> 10 bits at exponent 0
-    const unsigned half = man >> shift, rem = man & ((1u << shift) - 1), mid = 1u << (shift - 1);
-    return static_cast<unsigned short>(sign | (half + ((rem > mid || (rem == mid && (half & 1))) ? 1 : 0)));
-  }
-  const unsigned half = (static_cast<unsigned>(exp) << 10) | (man >> 13), rem = man & 0x1fffu;
-  return static_cast<unsigned short>(sign | (half + ((rem > 0x1000u || (rem == 0x1000u && (half & 1))) ? 1 : 0)));
-}
-
-static int ensure_gcc_table(seld::DeviceState* st) {
-  using namespace seld;
-  if (st->gcc_table) return kOk;
-  std::vector<unsigned short> host(kGmTableBytes / 2);
-  for (int part = 0; part < 2; ++part)
-    for (int tile = 0; tile < kGmLagTiles; ++tile)
-      for (int ks = 0; ks < kGmKSteps; ++ks)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int j = 0; j < 8; ++j)
-            host[((((part * kGmLagTiles + tile) * kGmKSteps + ks) * 64) + lane) * 8 + j] =
-                half_bits(static_cast<float>(gcc_table_value(part, tile, ks, lane, j)));
-  SELD_HIP_TRY(hipMalloc(&st->gcc_table, kGmTableBytes));
-  SELD_HIP_TRY(hipMemcpy(st->gcc_table, host.data(), kGmTableBytes, hipMemcpyHostToDevice));
-  return kOk;
-}
-
 int seld_gcc_phat(const float* spec_complex, int64_t N, int64_t C, int64_t F, float* out, int64_t sN, int64_t sC,
                   int64_t sM, int64_t sT, void* stream_) {
   using namespace seld;
@@ -683,8 +683,6 @@ int seld_gcc_phat(const float* spec_complex, int64_t N, int64_t C, int64_t F, fl
   // the matrix-core kernel stores four consecutive lags as one vector: unit lag stride, 16-byte aligned rows
   const bool vector_rows = sM == 1 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && sN % 4 == 0 && sC % 4 == 0 && sT % 4 == 0;
   if (!use_fft && vector_rows) {
-    const int rc = ensure_gcc_table(st);
-    if (rc != kOk) return rc;
     GccMfmaArgs a{spec_complex, out, N, C, F, sN, sC, sM, sT, st->gcc_table, nullptr};
     static const bool want_stamps = getenv("SELD_GCC_STAMPS") != nullptr;      // developer instrumentation
     if (want_stamps) SELD_HIP_TRY(hipMalloc(&a.stamps, 64 * kGmWaves * 5 * sizeof(long long)));
