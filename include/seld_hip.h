@@ -234,10 +234,12 @@ int seld_conv_tail_backward(const void* x, const void* residual, const void* dy,
 /* nn.Conv1d(D, D, K, padding=(K-1)/2, groups=D) evaluated in the channels-last layout of the surrounding layers:
  * x, y [B][T][D] (bf16 when is_bf16, else fp32), weight [D][K] fp32, bias [D] fp32 or NULL, odd K <= 31, D % 64 == 0.
  * flip_taps != 0 evaluates the data gradient (dx from dy with the taps reversed; pass bias = NULL).
- * seld_dwconv1d_wgrad: partial [B][D][32] fp32 -- per batch row, slots 0..K-1 = sum_t dy[t] x[t + k - pad], slot 31 =
- * sum_t dy[t]; the caller adds the batch rows (dweight = partial.sum(0)[:, :K], dbias = partial.sum(0)[:, 31]). */
+ * seld_dwconv1d_wgrad: partial [R][D][32] fp32 with R = seld_dwconv1d_wgrad_rows(B, T) (one row per batch row and
+ * 50-step time chunk) -- slots 0..K-1 = sum_t dy[t] x[t + k - pad] over the chunk, slot 31 = sum_t dy[t]; the caller adds
+ * the rows (dweight = partial.sum(0)[:, :K], dbias = partial.sum(0)[:, 31]). */
 int seld_dwconv1d(const void* x, int is_bf16, const float* weight, const float* bias, int64_t B, int64_t T, int D, int K,
                   int flip_taps, void* y, void* stream);
+int64_t seld_dwconv1d_wgrad_rows(int64_t B, int64_t T);
 int seld_dwconv1d_wgrad(const void* x, const void* dy, int is_bf16, int64_t B, int64_t T, int D, int K, float* partial,
                         void* stream);
 

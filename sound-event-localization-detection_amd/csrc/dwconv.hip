@@ -8,8 +8,8 @@
 // step and walks the K taps (rows of the same 64-channel column block: L1 / L2 hits), the K x 64 weights of the block
 // sit in LDS.  HBM-bound in principle (read x, write y: 4 B per element); at 4 MB per tensor the launches are
 // latency-sized (a few microseconds).  Backward data = the same kernel with the taps flipped; backward weight = one
-// block per (batch row, 64 channels) that slides an 8-tap register window over time (fp32 partials per batch row,
-// summed by the caller: deterministic).
+// block per (batch row, 64 channels, 50 time steps) that slides an 8-tap register window over its LDS-staged chunk
+// (fp32 partials per block, summed by the caller: deterministic).
 #include <hip/hip_bf16.h>
 
 #include "seld_common.h"
@@ -91,29 +91,61 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const void* __restrict__ x,
   Dw8<T>::store(y, (row0 + t) * D + d0 + 8 * cg, acc);
 }
 
-// dw_partial[b][d][k] = sum_t dy[b][t][d] x[b][t + k - pad][d]  (k < K);  slot 31 of every (b, d) = sum_t dy (bias)
-// grid (D / 64, B), 256 threads = 64 channels x 4 tap groups of 8.
+// dw_partial[row][d][k] = sum_{t in chunk} dy[b][t][d] x[b][t + k - pad][d]  (k < K);  slot 31 = sum_t dy (bias);
+// row = b * chunks + chunk.  grid (D / 64, B, chunks), 256 threads = 64 channels x 4 tap groups of 8.
+// Round 1 ran one block per (batch row, 64 channels) that walked all T steps with two dependent 2-byte loads per step:
+// 128 blocks, 250 serial HBM/L2 round trips, 119 us for 4 MB.  Now a block takes kDwChunk time steps: the chunk of dy and
+// the chunk + halo of x are staged in LDS once (16-byte loads, 8 channels per lane), then every thread slides its 8-tap
+// register window over the chunk from LDS (conflict free: consecutive lanes = consecutive channels).
+constexpr int kDwChunk = 50;
+
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const void* __restrict__ x, const void* __restrict__ dy,
                                                            int Tn, int D, int K, float* __restrict__ partial) {
+  __shared__ float xs[kDwChunk + kDwMaxTaps][64];        // rows t0 - pad .. t0 + chunk + pad (zero outside the sequence)
+  __shared__ float gs[kDwChunk][64];
   const int tid = threadIdx.x;
-  const int c = tid & 63, kg = tid >> 6;
-  const int d = blockIdx.x * 64 + c;
+  const int d0 = blockIdx.x * 64;
   const int pad = (K - 1) / 2;
+  const int t0 = blockIdx.z * kDwChunk;
+  const int len = Tn - t0 < kDwChunk ? Tn - t0 : kDwChunk;
   const long row0 = static_cast<long>(blockIdx.y) * Tn;
+  // stage: 8 lanes cover the 64 channels of a row
+  for (int i = tid; i < (kDwChunk + kDwMaxTaps) * 8; i += 256) {
+    const int r = i >> 3, cg = i & 7;
+    const int ti = t0 - pad + r;
+    float v[8];
+    if (r < len + 2 * pad && ti >= 0 && ti < Tn) Dw8<T>::load(x, (row0 + ti) * D + d0 + 8 * cg, v);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xs[r][8 * cg + j] = v[j];
+  }
+  for (int i = tid; i < kDwChunk * 8; i += 256) {
+    const int r = i >> 3, cg = i & 7;
+    float v[8];
+    if (r < len) Dw8<T>::load(dy, (row0 + t0 + r) * D + d0 + 8 * cg, v);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gs[r][8 * cg + j] = v[j];
+  }
+  __syncthreads();
+  const int c = tid & 63, kg = tid >> 6;
   float acc[8], win[8], bsum = 0.0f;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
-  // window of x[t + k - pad] for k = 8 kg + j at t = 0
-#pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int ti = 8 * kg + j - pad;
-    win[j] = (ti >= 0 && ti < Tn) ? Dw8<T>::load1(x, (row0 + ti) * D + d) : 0.0f;
+    acc[j] = 0.0f;
+    win[j] = xs[8 * kg + j][c];                           // x[t0 + (8 kg + j) - pad]
   }
-  for (int t = 0; t < Tn; ++t) {
-    const float g = Dw8<T>::load1(dy, (row0 + t) * D + d);
-    const int tn = t + 1 + 8 * kg + 7 - pad;              // element entering the window for step t + 1
-    const float next = (tn >= 0 && tn < Tn) ? Dw8<T>::load1(x, (row0 + tn) * D + d) : 0.0f;
+#pragma unroll 5
+  for (int t = 0; t < kDwChunk; ++t) {                   // rows past `len` hold zero gradients
+    const float g = gs[t][c];
+    const float next = xs[t + 8 * kg + 8][c];
     bsum += g;
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = fmaf(g, win[j], acc[j]);
@@ -121,7 +153,8 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const void* __restric
     for (int j = 0; j < 7; ++j) win[j] = win[j + 1];
     win[7] = next;
   }
-  float* out = partial + (static_cast<long>(blockIdx.y) * D + d) * kDwMaxTaps + 8 * kg;
+  const long prow = static_cast<long>(blockIdx.y) * gridDim.z + blockIdx.z;
+  float* out = partial + (prow * D + d0 + c) * kDwMaxTaps + 8 * kg;
 #pragma unroll
   for (int j = 0; j < 8; ++j) out[j] = acc[j];
   if (kg == 3) out[7] = bsum;                             // slot 31: never a tap (K <= 31)
@@ -162,7 +195,7 @@ int seld_dwconv1d_wgrad(const void* x, const void* dy, int is_bf16, int64_t B, i
   if (int rc = dw_check("seld_dwconv1d_wgrad", B, T, D, K)) return rc;
   if (!x || !dy || !partial) return fail(kErrInvalidArgument, "seld_dwconv1d_wgrad: null pointer");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const dim3 grid(static_cast<unsigned>(D / 64), static_cast<unsigned>(B));
+  const dim3 grid(static_cast<unsigned>(D / 64), static_cast<unsigned>(B), static_cast<unsigned>((T + kDwChunk - 1) / kDwChunk));
   if (is_bf16) hipLaunchKernelGGL(dwconv_wgrad_kernel<__hip_bfloat16>, grid, dim3(256), 0, stream, x, dy,
                                   static_cast<int>(T), D, K, partial);
   else hipLaunchKernelGGL(dwconv_wgrad_kernel<float>, grid, dim3(256), 0, stream, x, dy, static_cast<int>(T), D, K,
@@ -170,5 +203,7 @@ int seld_dwconv1d_wgrad(const void* x, const void* dy, int is_bf16, int64_t B, i
   SELD_HIP_TRY(hipGetLastError());
   return kOk;
 }
+
+int64_t seld_dwconv1d_wgrad_rows(int64_t B, int64_t T) { return B * ((T + seld::kDwChunk - 1) / seld::kDwChunk); }
 
 }  // extern "C"

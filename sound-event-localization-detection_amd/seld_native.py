@@ -92,6 +92,8 @@ def _declare(lib):
                                             _ptr, _ptr]
     lib.seld_dwconv1d.argtypes = [_ptr, _int, _ptr, _ptr, _i64, _i64, _int, _int, _int, _ptr, _ptr]
     lib.seld_dwconv1d_wgrad.argtypes = [_ptr, _ptr, _int, _i64, _i64, _int, _int, _ptr, _ptr]
+    lib.seld_dwconv1d_wgrad_rows.argtypes = [_i64, _i64]
+    lib.seld_dwconv1d_wgrad_rows.restype = ctypes.c_int64
     lib.seld_gru_to_tile.argtypes = [_ptr, _int, _i64, _i64, _int, _ptr, _ptr]
     lib.seld_gru_from_pair_tile.argtypes = [_ptr, _int, _i64, _i64, _ptr, _ptr, _ptr]
     lib.seld_gru_previous_state.argtypes = [_ptr, _int, _i64, _i64, _ptr, _ptr]
@@ -612,7 +614,8 @@ def dwconv1d_wgrad(x: torch.Tensor, dy: torch.Tensor, k: int):
     """-> (dweight [D, K] fp32, dbias [D] fp32) of the depthwise convolution."""
     x, dy = x.contiguous(), dy.to(x.dtype).contiguous()
     b, t, d = x.shape
-    partial = torch.empty((b, d, 32), dtype=torch.float32, device=x.device)
+    rows = int(load_library().seld_dwconv1d_wgrad_rows(b, t))          # one per batch row and 50-step time chunk
+    partial = torch.empty((rows, d, 32), dtype=torch.float32, device=x.device)
     with _device_guard(ensure_init(x.device)):
         check(load_library().seld_dwconv1d_wgrad(_p(x), _p(dy), int(x.dtype == torch.bfloat16), b, t, d, k, _p(partial),
                                                  _stream_ptr(x.device)), "seld_dwconv1d_wgrad")
