@@ -198,6 +198,13 @@ int seld_gru_bias_grads(const float* partial, int64_t tiles, int64_t H, float* d
 int seld_sum_chunks(const void* partial, int in_is_bf16, int64_t chunks, int64_t count, void* out, int out_is_bf16,
                     void* stream);
 
+/* out[n] = sum over r of g[r][n]: the bias gradient of an nn.Linear (autograd for trainer.py:178) from the [rows][n_cols]
+ * output gradient, bf16 or fp32, n_cols % 8 == 0, 16-byte aligned.  Two launches: row blocks summed in parallel into
+ * `partial` [seld_column_sums_blocks(rows, n_cols)][n_cols] fp32 (caller-owned), then added in a fixed order. */
+int64_t seld_column_sums_blocks(int64_t rows, int64_t n_cols);
+int seld_column_sums(const void* g, int in_is_bf16, int64_t rows, int64_t n_cols, float* partial, void* out, int out_is_bf16,
+                     void* stream);
+
 /* dW_hh [2][3H][H] of nn.GRU from the two chunked products the host forms over both directions at once:
  * p_gi [chunks][2][3][H][2][H] = (da_r, da_z, da_n)^T h_prev, p_n [chunks][2][H][2][H] = (da_n r)^T h_prev; the blocks
  * with matching directions (and, of p_gi, the r and z gates) are summed over the chunks and written in place. */

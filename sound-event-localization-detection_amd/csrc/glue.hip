@@ -93,6 +93,77 @@ __global__ __launch_bounds__(kGlueThreads) void sum_chunks_kernel(const void* __
     if (i0 + j < count) store_from_float(out, i0 + j, out_bf16 != 0, acc[j]);
 }
 
+// partial[y][n] = sum over the rows of row block y of g[r][n]: stage 1 of a column sum of a tall matrix (the bias
+// gradient of every nn.Linear: 8000 rows x 256..9072 columns).  The framework's reduce kernel takes 16 - 36 us for these
+// shapes whatever the width (few, long threads); here the rows are cut into blocks so that ~1000 workgroups stream the
+// matrix with 16-byte loads, and column_finish_kernel adds the row blocks in a fixed order (deterministic, fp32).
+// 256 threads = 32 column groups of 8 columns x 8 row slots; grid (ceil(N / 256), row blocks).
+__global__ __launch_bounds__(kGlueThreads) void column_partials_kernel(const void* __restrict__ g, int in_bf16, long rows,
+                                                                       int n_cols, int rows_per_block,
+                                                                       float* __restrict__ partial) {
+  __shared__ float red[8][257];
+  const int tid = threadIdx.x;
+  const int cg = tid & 31, slot = tid >> 5;
+  const int col0 = blockIdx.x * 256 + cg * 8;
+  const long r0 = static_cast<long>(blockIdx.y) * rows_per_block;
+  const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+  if (col0 < n_cols) {
+    auto add_row = [&](long r) {
+      const long base = r * n_cols + col0;
+      if (in_bf16) {
+        const uint4 v = *reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(g) + base);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[2 * j] += __uint_as_float(w[j] << 16);
+          acc[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+        }
+      } else {
+        const float4* q = reinterpret_cast<const float4*>(static_cast<const float*>(g) + base);
+        const float4 a = q[0], b = q[1];
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+        acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+      }
+    };
+    long r = r0 + slot;
+    for (; r + 24 < r1; r += 32) {                          // four independent 16-byte loads in flight
+      add_row(r);
+      add_row(r + 8);
+      add_row(r + 16);
+      add_row(r + 24);
+    }
+    for (; r < r1; r += 8) add_row(r);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[slot][cg * 8 + j] = acc[j];
+  __syncthreads();
+  const int col = blockIdx.x * 256 + tid;
+  if (col < n_cols) {
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum += red[k][tid];
+    partial[static_cast<long>(blockIdx.y) * n_cols + col] = sum;
+  }
+}
+
+// out[n] = sum over the row blocks of partial[y][n] (fixed order): stage 2.  256 threads = 64 columns x 4 row slots.
+__global__ __launch_bounds__(kGlueThreads) void column_finish_kernel(const float* __restrict__ partial, int blocks, int n_cols,
+                                                                     void* __restrict__ out, int out_bf16) {
+  __shared__ float red[4][64];
+  const int tid = threadIdx.x;
+  const int c = tid & 63, slot = tid >> 6;
+  const int col = blockIdx.x * 64 + c;
+  float sum = 0.0f;
+  if (col < n_cols)
+    for (int y = slot; y < blocks; y += 4) sum += partial[static_cast<long>(y) * n_cols + col];
+  red[slot][c] = sum;
+  __syncthreads();
+  if (slot == 0 && col < n_cols) store_from_float(out, col, out_bf16 != 0, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+}
+
 // dW_hh[d][g][u][k] from the two wasteful-but-well-shaped products the host forms (seld_gru._BiGRULayer.backward):
 //   p_gi[c][d][g][u][d'][k] = chunk c of  dgi^T h_prev      (g = 0..2; only d' == d and g < 2 are wanted)
 //   p_n [c][d][u][d'][k]    = chunk c of  (da_n r)^T h_prev (only d' == d)
@@ -181,6 +252,34 @@ int seld_sum_chunks(const void* partial, int in_is_bf16, int64_t chunks, int64_t
                        dim3(kGlueThreads), 0, stream, partial, in_is_bf16, static_cast<int>(chunks),
                        static_cast<long>(count), out, out_is_bf16);
   }
+  SELD_HIP_TRY(hipGetLastError());
+  return kOk;
+}
+
+int64_t seld_column_sums_blocks(int64_t rows, int64_t n_cols) {
+  const long col_blocks = (n_cols + 255) / 256;
+  long rb = 1024 / col_blocks;
+  if (rb < 8) rb = 8;
+  if (rb > 64) rb = 64;
+  if (rb > rows) rb = rows;
+  return rb;
+}
+
+int seld_column_sums(const void* g, int in_is_bf16, int64_t rows, int64_t n_cols, float* partial, void* out, int out_is_bf16,
+                     void* stream_) {
+  using namespace seld;
+  if (!current_state()) return kErrNotInitialised;
+  if (rows <= 0 || n_cols <= 0 || !g || !partial || !out) return fail(kErrInvalidArgument, "seld_column_sums: bad argument");
+  if (n_cols % 8 != 0 || (reinterpret_cast<uintptr_t>(g) & 15) != 0)
+    return fail(kErrUnsupported, "seld_column_sums: the column count must be a multiple of 8 and the matrix 16-byte aligned");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const long rb = seld_column_sums_blocks(rows, n_cols);
+  const long rows_per_block = (rows + rb - 1) / rb;
+  hipLaunchKernelGGL(column_partials_kernel, dim3(static_cast<unsigned>((n_cols + 255) / 256), static_cast<unsigned>(rb)),
+                     dim3(kGlueThreads), 0, stream, g, in_is_bf16, static_cast<long>(rows), static_cast<int>(n_cols),
+                     static_cast<int>(rows_per_block), partial);
+  hipLaunchKernelGGL(column_finish_kernel, dim3(static_cast<unsigned>((n_cols + 63) / 64)), dim3(kGlueThreads), 0, stream,
+                     partial, static_cast<int>(rb), static_cast<int>(n_cols), out, out_is_bf16);
   SELD_HIP_TRY(hipGetLastError());
   return kOk;
 }

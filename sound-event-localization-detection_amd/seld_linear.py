@@ -61,6 +61,17 @@ def tall_chunks(a, c, chunks=None):
     return torch.bmm(av, cv)
 
 
+def column_sum(g2, out):
+    """out[n] = sum_r g2[r, n] with fp32 accumulation: the bias gradient.  csrc/glue.hip (two launches, ~1000 workgroups
+    streaming the matrix) where it applies -- the framework's reduction takes 16 - 36 us for these 8000-row shapes whatever
+    their width, and a Conformer iteration has 19 of them."""
+    import os
+    import seld_native
+    if os.environ.get("SELD_COLUMN_SUMS", "1") != "0" and seld_native.column_sums_supported(g2, out):      # developer A/B switch
+        return seld_native.column_sums(g2, out)
+    return torch.sum(g2, dim=0, dtype=out.dtype, out=out)
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, overlap=False):
@@ -98,12 +109,12 @@ class _Linear(torch.autograd.Function):
                     if dw is not None:
                         tall_product(g2, x2, out=dw)
                     if db is not None:
-                        torch.sum(g2, dim=0, dtype=db.dtype, out=db)     # fp32 accumulation inside the reduction
+                        column_sum(g2, db)
 
                 seld_overlap.submit(grad.device, [t for t in (g2, x2, dw, db) if t is not None], job)
             else:
                 dw = tall_product(g2, x2, out_dtype=ctx.w_dtype) if want_w else None
-                db = torch.sum(g2, dim=0, dtype=ctx.b_dtype) if want_b else None     # accumulates in fp32
+                db = column_sum(g2, torch.empty((g2.shape[1],), dtype=ctx.b_dtype, device=grad.device)) if want_b else None
         if dx is not None and dx.dtype != ctx.in_dtype:
             dx = dx.to(ctx.in_dtype)
         return dx, dw, db, None

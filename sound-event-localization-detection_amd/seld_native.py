@@ -77,6 +77,9 @@ def _declare(lib):
     lib.seld_gru_bias_grads.argtypes = [_ptr, _i64, _i64, _ptr, _ptr, _ptr]
     lib.seld_sum_chunks.argtypes = [_ptr, _int, _i64, _i64, _ptr, _int, _ptr]
     lib.seld_gru_dwhh_finish.argtypes = [_ptr, _ptr, _int, _i64, _i64, _ptr, _int, _ptr]
+    lib.seld_column_sums.argtypes = [_ptr, _int, _i64, _i64, _ptr, _ptr, _int, _ptr]
+    lib.seld_column_sums_blocks.argtypes = [_i64, _i64]
+    lib.seld_column_sums_blocks.restype = ctypes.c_int64
     lib.seld_conv_weight_flip_transpose.argtypes = [_ptr, _int, _i64, _i64, _ptr, _ptr]
     lib.seld_layernorm_supported.argtypes = [_i64]
     lib.seld_layernorm_workspace_floats.restype = _i64
@@ -809,6 +812,26 @@ def sum_chunks(partial: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     with _device_guard(ensure_init(partial.device)):
         check(load_library().seld_sum_chunks(_p(partial), _is_bf16(partial), partial.shape[0], out.numel(), _p(out),
                                              _is_bf16(out), _stream_ptr(partial.device)), "seld_sum_chunks")
+    return out
+
+
+def column_sums_supported(g: torch.Tensor, out: torch.Tensor) -> bool:
+    return (g.is_cuda and g.dim() == 2 and g.is_contiguous() and out.is_contiguous() and g.shape[1] % 8 == 0
+            and g.dtype in (torch.float32, torch.bfloat16) and out.dtype in (torch.float32, torch.bfloat16)
+            and out.numel() == g.shape[1] and g.data_ptr() % 16 == 0 and g.shape[0] > 0)
+
+
+def column_sums(g: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[n] = sum_r g[r, n] accumulated in fp32 (the bias gradient of a Linear from its [rows, N] output gradient)."""
+    if not column_sums_supported(g, out):
+        raise SeldNativeError("column_sums: g [rows, N] contiguous bf16 / fp32 with N % 8 == 0, out [N] contiguous")
+    lib = load_library()
+    rows, n = g.shape
+    blocks = int(lib.seld_column_sums_blocks(rows, n))
+    partial = torch.empty((blocks, n), dtype=torch.float32, device=g.device)
+    with _device_guard(ensure_init(g.device)):
+        check(lib.seld_column_sums(_p(g), _is_bf16(g), rows, n, _p(partial), _p(out), _is_bf16(out), _stream_ptr(g.device)),
+              "seld_column_sums")
     return out
 
 

@@ -49,3 +49,24 @@ def test_bf16_autocast_tracks_fp32_reference(gpu_device):
     a = torch.randn(77, 33, device=gpu_device)
     c = torch.randn(77, 5, device=gpu_device)
     assert torch.allclose(tall_product(a, c), a.t() @ c, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("rows,cols", [(8000, 256), (8000, 512), (8000, 9072), (37, 8), (1, 1024), (4099, 2048)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_column_sums_match_fp64(gpu_device, rows, cols, dtype):
+    """csrc/glue.hip column sums (the bias gradient of every Linear): fp32 accumulation, deterministic, against a float64
+    sum of the same (rounded) inputs; output in either dtype."""
+    import seld_native
+    torch.manual_seed(rows + cols)
+    g = torch.randn(rows, cols, device=gpu_device).to(dtype)
+    ref = g.double().sum(0)
+    scale = g.double().abs().sum(0).clamp_min(1e-6)
+    for out_dtype in (torch.float32, torch.bfloat16):
+        out = torch.empty(cols, dtype=out_dtype, device=gpu_device)
+        seld_native.column_sums(g, out)
+        tol = 2e-6 if out_dtype == torch.float32 else 4e-3
+        assert ((out.double() - ref).abs() / scale).max().item() <= tol if out_dtype == torch.float32 else \
+            ((out.double() - ref).abs() <= 4e-3 * ref.abs() + 1e-2).all()
+        again = torch.empty_like(out)
+        seld_native.column_sums(g, again)
+        assert torch.equal(out, again)

@@ -33,3 +33,8 @@ for n in (256, 512, 1024, 2048, 9072):
     ref = g.float().sum(0)
     err_b = (torch.mm(ones, g)[0].float() - ref).abs().max().item() / ref.abs().max().item()
     print(f"N={n:5d}: torch.sum {a:6.1f} us   ones @ g {b:6.1f} us (rel err {err_b:.1e})   mv {c:6.1f} us")
+for n in (256, 512, 1024, 2048, 9072):
+    g = torch.randn(8000, n, device=dev).to(torch.bfloat16)
+    out = torch.empty(n, device=dev, dtype=torch.bfloat16)
+    d = timeit(lambda: seld_native.column_sums(g, out))
+    print(f"N={n:5d}: seld column_sums {d:6.1f} us (incl. the partial allocation and two launches)")
