@@ -210,7 +210,15 @@ __global__ __launch_bounds__(kFinalThreads) void tail_stats_final_kernel(const v
   }
 }
 
-// kPool: 2 = MaxPool2d((1,2)) over adjacent rows; 1 = no pooling; 3 = no pooling + residual add before the ReLU
+// SiLU (Swish) and its derivative at z, for mode 4
+__device__ __forceinline__ float silu_f(float z) { return z * __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
+__device__ __forceinline__ float silu_grad_f(float z) {
+  const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+  return s * fmaf(z, 1.0f - s, 1.0f);
+}
+
+// kPool: 2 = MaxPool2d((1,2)) over adjacent rows; 1 = no pooling; 3 = no pooling + residual add before the ReLU;
+// 4 = no pooling, SiLU instead of ReLU (BatchNorm1d -> Swish of the Conformer convolution module, model_conformer.py:71-96)
 // (the tail of a ResNet bottleneck, resnet50_model.py:30-52: relu(bn3(conv3(y)) + shortcut)); in mode 3 the second
 // operand row `x1` carries the residual, rounded into the activation dtype after the add like the unfused modules.
 template <typename T, int kPool>
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_apply_kernel(const void* __
       float z = Row8<T>::round(fmaf(x0[i], a[i], b[i]));
       if (kPool == 2) z = fmaxf(z, Row8<T>::round(fmaf(x1[i], a[i], b[i])));
       if (kPool == 3) z = Row8<T>::round(z + x1[i]);
-      out[i] = fmaxf(z, 0.0f);                     // max(relu(z0), relu(z1)) == relu(max(z0, z1))
+      out[i] = kPool == 4 ? silu_f(z) : fmaxf(z, 0.0f);     // max(relu(z0), relu(z1)) == relu(max(z0, z1))
     }
     Row8<T>::store(y, o * C + 8 * cg, out);
   };
@@ -302,9 +310,15 @@ __global__ __launch_bounds__(kTailThreads) void tail_bwd_reduce_kernel(const voi
   auto one = [&](const float (&x0)[8], const float (&x1)[8], const float (&g)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int sel = route<T, kPool>(x0[i], x1[i], a[i], b[i]);
-      const float dz = sel >= 0 ? g[i] : 0.0f;
-      const float xs = sel == 1 ? x1[i] : x0[i];
+      float dz, xs;
+      if (kPool == 4) {
+        dz = g[i] * silu_grad_f(Row8<T>::round(fmaf(x0[i], a[i], b[i])));
+        xs = x0[i];
+      } else {
+        const int sel = route<T, kPool>(x0[i], x1[i], a[i], b[i]);
+        dz = sel >= 0 ? g[i] : 0.0f;
+        xs = sel == 1 ? x1[i] : x0[i];
+      }
       acc[0][i] += dz;
       acc[1][i] = fmaf(dz, xs - mean[i], acc[1][i]);
     }
@@ -397,8 +411,12 @@ __global__ __launch_bounds__(kTailThreads) void tail_bwd_apply_kernel(const void
     float d0[8], d1[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int sel = route<T, kPool>(x0[i], x1[i], a[i], b[i]);
       const float base0 = fmaf(q[i], x0[i], p[i]);
+      if (kPool == 4) {
+        d0[i] = fmaf(a[i], g[i] * silu_grad_f(Row8<T>::round(fmaf(x0[i], a[i], b[i]))), base0);
+        continue;
+      }
+      const int sel = route<T, kPool>(x0[i], x1[i], a[i], b[i]);
       d0[i] = sel == 0 ? fmaf(a[i], g[i], base0) : base0;
       if (kPool == 2) {
         const float base1 = fmaf(q[i], x1[i], p[i]);
@@ -436,10 +454,11 @@ __global__ __launch_bounds__(kTailThreads) void tail_bwd_apply_kernel(const void
 
 static int tail_check(const char* who, int64_t rows, int C, int pool) {
   if (rows <= 0 || C <= 0) return fail(kErrInvalidArgument, std::string(who) + ": rows and C must be positive");
-  if (pool != 1 && pool != 2) return fail(kErrUnsupported, std::string(who) + ": pool must be 1 (none) or 2 (MaxPool2d((1,2)))");
+  if (pool != 1 && pool != 2 && pool != 4)
+    return fail(kErrUnsupported, std::string(who) + ": pool must be 1 (none), 2 (MaxPool2d((1,2))) or 4 (none, SiLU)");
   if (C % 8 != 0 || kTailThreads % (C / 8) != 0)
     return fail(kErrUnsupported, std::string(who) + ": C must be 8 * (a divisor of 256)");
-  if (rows % pool != 0) return fail(kErrUnsupported, std::string(who) + ": rows must be a multiple of the pool width");
+  if (pool == 2 && rows % 2 != 0) return fail(kErrUnsupported, std::string(who) + ": rows must be a multiple of the pool width");
   return kOk;
 }
 
@@ -466,7 +485,7 @@ int seld_conv_tail_forward(const void* x, const void* residual, int is_bf16, int
   DeviceState* st = current_state();
   if (!st) return kErrNotInitialised;
   if (int rc = tail_check("seld_conv_tail_forward", rows, C, pool)) return rc;
-  if (residual && pool != 1) return fail(kErrUnsupported, "seld_conv_tail_forward: a residual needs pool = 1");
+  if (residual && pool != 1) return fail(kErrUnsupported, "seld_conv_tail_forward: a residual needs pool = 1");   // (mode 4: none)
   if (!x || !y || !mean_invstd || !scale_shift || (training && !workspace))
     return fail(kErrInvalidArgument, "seld_conv_tail_forward: null pointer");
   if (!training && (!running_mean || !running_var))
@@ -486,7 +505,7 @@ int seld_conv_tail_forward(const void* x, const void* residual, int is_bf16, int
   else hipLaunchKernelGGL(tail_stats_final_kernel<float>, fgrid, dim3(kFinalThreads), 0, stream, x,
                           static_cast<long>(rows), C, workspace, nblocks, weight, bias, running_mean, running_var,
                           momentum, eps, training, mean_invstd, scale_shift);
-  const long out_rows = rows / pool;
+  const long out_rows = pool == 2 ? rows / 2 : rows;
   const dim3 grid(tail_grid(st, out_rows, C));
   const int mode = residual ? 3 : pool;
 #define SELD_TAIL_APPLY(T, P)                                                                                     \
@@ -495,10 +514,12 @@ int seld_conv_tail_forward(const void* x, const void* residual, int is_bf16, int
   if (is_bf16) {
     if (mode == 2) SELD_TAIL_APPLY(__hip_bfloat16, 2);
     else if (mode == 3) SELD_TAIL_APPLY(__hip_bfloat16, 3);
+    else if (mode == 4) SELD_TAIL_APPLY(__hip_bfloat16, 4);
     else SELD_TAIL_APPLY(__hip_bfloat16, 1);
   } else {
     if (mode == 2) SELD_TAIL_APPLY(float, 2);
     else if (mode == 3) SELD_TAIL_APPLY(float, 3);
+    else if (mode == 4) SELD_TAIL_APPLY(float, 4);
     else SELD_TAIL_APPLY(float, 1);
   }
 #undef SELD_TAIL_APPLY
@@ -519,7 +540,7 @@ int seld_conv_tail_backward(const void* x, const void* residual, const void* dy,
     return fail(kErrInvalidArgument, "seld_conv_tail_backward: null pointer");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int nblocks = kTailStatBlocks;
-  const long out_rows = rows / pool;
+  const long out_rows = pool == 2 ? rows / 2 : rows;
   float* coef = workspace + 2L * nblocks * C;        // [2][C] after the partial sums
 #define SELD_TAIL_BWD(T, P)                                                                                      \
   do {                                                                                                           \
@@ -535,10 +556,12 @@ int seld_conv_tail_backward(const void* x, const void* residual, const void* dy,
   if (is_bf16) {
     if (mode == 2) SELD_TAIL_BWD(__hip_bfloat16, 2);
     else if (mode == 3) SELD_TAIL_BWD(__hip_bfloat16, 3);
+    else if (mode == 4) SELD_TAIL_BWD(__hip_bfloat16, 4);
     else SELD_TAIL_BWD(__hip_bfloat16, 1);
   } else {
     if (mode == 2) SELD_TAIL_BWD(float, 2);
     else if (mode == 3) SELD_TAIL_BWD(float, 3);
+    else if (mode == 4) SELD_TAIL_BWD(float, 4);
     else SELD_TAIL_BWD(float, 1);
   }
 #undef SELD_TAIL_BWD

@@ -91,3 +91,28 @@ def bn_relu(bn, x, pool=1, residual=None):
 
 def conv_tail(block, x):
     return bn_relu(block.bn, x, 2 if block.pool is not None else 1)
+
+
+def bn1d_silu_applicable(bn, x):
+    """Can the fused kernels stand in for ``silu(bn(x))`` on a [rows, D] activation (BatchNorm1d -> Swish of the
+    Conformer convolution module, model_conformer.py:71-96, evaluated channels-last by seld_dwconv)?"""
+    if not (enabled and x.is_cuda and x.dim() == 2 and x.is_contiguous() and type(bn) is nn.BatchNorm1d and bn.affine
+            and bn.track_running_stats and bn.momentum is not None and x.dtype in (torch.float32, torch.bfloat16)):
+        return False
+    if not seld_native.conv_tail_supported(x.shape[1]):
+        return False
+    return bn.training or not (torch.is_grad_enabled() and x.requires_grad)
+
+
+def bn1d_silu(bn, x):
+    """silu(bn(x)) for x [rows, D]: the tail kernels in mode 4 (statistics pass + apply pass; the backward pass recomputes
+    the normalised value and the SiLU derivative from x), on the [rows, D, 1, 1] channels-last view of the same memory."""
+    if bn.training:
+        if _collected is not None:
+            _collected.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
+    rows, d = x.shape
+    x4 = x.view(rows, 1, 1, d).permute(0, 3, 1, 2)
+    y4 = _ConvTail.apply(x4, None, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, bn.training, 4)
+    return y4.permute(0, 2, 3, 1).reshape(rows, d)

@@ -62,7 +62,11 @@ def conv_module_forward(module, x):
     if low:
         y = y.to(torch.get_autocast_dtype("cuda"))
     y = _DepthwiseConv1d.apply(y, dw.weight, dw.bias)
-    y = module.batch_norm(y.reshape(b * t, d)).view(b, t, d)               # BatchNorm1d over (B, T) per channel
-    y = module.swish(y)
+    import seld_convtail
+    y2 = y.reshape(b * t, d)
+    if type(module.swish).__name__ in ("Swish", "SiLU") and seld_convtail.bn1d_silu_applicable(module.batch_norm, y2):
+        y = seld_convtail.bn1d_silu(module.batch_norm, y2).view(b, t, d)    # BatchNorm1d -> Swish in two passes each way
+    else:
+        y = module.swish(module.batch_norm(y2).view(b, t, d))               # BatchNorm1d over (B, T) per channel
     y = _Linear.apply(y, p2.weight.squeeze(-1), p2.bias)
     return x + module.dropout(y)

@@ -556,10 +556,11 @@ def conv_tail_forward(x, weight, bias, running_mean, running_var, momentum, eps,
             raise ValueError("conv_tail: the residual must match x and needs pool = 1")
         _tail_view(residual)
     b, _, t, f = x.shape
-    if f % pool:
+    width = 2 if pool == 2 else 1                   # pool = 4: no pooling, SiLU instead of ReLU (BatchNorm1d -> Swish)
+    if f % width:
         raise ValueError("conv_tail: the frequency extent must be a multiple of the pool width")
     index = ensure_init(x.device)
-    y = torch.empty((b, c, t, f // pool), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    y = torch.empty((b, c, t, f // width), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     stats = torch.empty((2, 2, c), dtype=torch.float32, device=x.device)
     lib = load_library()
     ws = torch.empty(lib.seld_conv_tail_workspace_floats(c), dtype=torch.float32, device=x.device)

@@ -229,3 +229,38 @@ def test_resnet_bottleneck_uses_fused_tails(gpu_device):
         assert (p.grad - q.grad).abs().max().item() <= 5e-4 * (q.grad.abs().max().item() + 1e-6), n
     for (n, p), (_, q) in zip(blk.named_buffers(), ref.named_buffers()):
         assert torch.allclose(p.float(), q.float(), rtol=1e-4, atol=1e-5), n
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,d", [(8000, 256), (8000, 512), (1000, 64), (37, 128)])
+def test_bn1d_silu_matches_stock_modules(gpu_device, rows, d, dtype):
+    """Tail mode 4 (csrc/convtail.hip): BatchNorm1d -> Swish of the Conformer convolution module (model_conformer.py:71-96)
+    against the stock modules in fp32 on the same device -- output, running statistics, dx, dweight, dbias."""
+    import seld_convtail
+    torch.manual_seed(rows + d)
+    x = (torch.randn(rows, d, device=gpu_device) * 1.5 + 0.3)
+    dy = torch.randn(rows, d, device=gpu_device)
+    ref_bn = nn.BatchNorm1d(d).to(gpu_device)
+    with torch.no_grad():
+        ref_bn.weight.uniform_(0.5, 1.5)
+        ref_bn.bias.uniform_(-0.5, 0.5)
+    bn = nn.BatchNorm1d(d).to(gpu_device)
+    bn.load_state_dict(ref_bn.state_dict())
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.silu(ref_bn(xr))
+    yr.backward(dy)
+    xl = x.to(dtype).requires_grad_(True)
+    assert seld_convtail.bn1d_silu_applicable(bn, xl)
+    y = seld_convtail.bn1d_silu(bn, xl)
+    y.backward(dy.to(dtype))
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    scale = yr.abs().max().item()
+    assert (y.float() - yr).abs().max().item() <= tol * scale
+    assert torch.allclose(bn.running_mean, ref_bn.running_mean, rtol=1e-5 if dtype == torch.float32 else 1e-2, atol=1e-3)
+    assert torch.allclose(bn.running_var, ref_bn.running_var, rtol=1e-4 if dtype == torch.float32 else 2e-2, atol=1e-3)
+    assert int(bn.num_batches_tracked) == 1
+    rel = lambda a, b: ((a.float() - b).norm() / b.norm().clamp_min(1e-12)).item()
+    gtol = 1e-4 if dtype == torch.float32 else 3e-2
+    assert rel(xl.grad, xr.grad) <= gtol
+    assert rel(bn.weight.grad, ref_bn.weight.grad) <= gtol
+    assert rel(bn.bias.grad, ref_bn.bias.grad) <= gtol
