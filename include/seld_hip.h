@@ -219,7 +219,8 @@ int seld_conv_weight_flip_transpose(const void* w, int elem_bytes, int64_t O, in
 /* ---- CNN block tail: BatchNorm2d -> ReLU -> MaxPool2d((1,2)) at model_crnn.py:5-17 (ConvBlock.forward) ---- */
 /* x: the convolution output in channels-last memory order = row-major [rows = B*T*F][C] (bf16 when is_bf16, else
  * fp32); the two frequency bins of a pooling pair are adjacent rows.  pool = 2: MaxPool2d((1,2)); pool = 1: no
- * pooling.  C must be 8 * (a divisor of 256); rows a multiple of pool.
+ * pooling; pool = 4: no pooling and SiLU instead of ReLU (BatchNorm1d -> Swish of the Conformer convolution module,
+ * model_conformer.py:71-96, rows = B*T).  C must be 8 * (a divisor of 256); rows even when pool = 2.
  * forward, training != 0: batch statistics (biased variance), running_mean / running_var updated with `momentum`
  *   (unbiased variance) exactly like nn.BatchNorm2d; training == 0: the running statistics are used.
  *   y [rows/pool][C] (dtype of x) = max over the pair of relu(weight * (x - mean) * invstd + bias), with the
