@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 /* ---- library state -------------------------------------------------------------------- */
-int seld_init(int device);            /* builds the constant tables (Hann, twiddles, sparse mel) */
+int seld_init(int device);            /* builds the constant tables (Hann, twiddles, sparse mel, GCC cosine / sine) */
 int seld_shutdown(void);
 int seld_version(void);
 const char* seld_last_error(void);
@@ -89,8 +89,10 @@ int seld_foa_intensity(const float* spec_complex, int64_t N, int64_t F, float* o
                        int64_t sM, int64_t sT, void* stream);
 
 /* GCC-PHAT of all C(C-1)/2 channel pairs (m < n, lexicographic) from spectra [N][C][F][481], 2 <= C <= 8:
- *   cc = irfft(R/|R|, 960) with R = conj(X_m) X_n;  out[n*sN + pair*sC + j*sM + t*sT] = cc[(j - 32) mod 960],
- *   j = 0..63 (lags -32..31). */
+ *   cc = irfft(R/|R|, 960) with R = conj(X_m) X_n (factor 1 where either channel's bin is silent, |X|^2 <= 1e-12);
+ *   out[n*sN + pair*sC + j*sM + t*sT] = cc[(j - 32) mod 960], j = 0..63 (lags -32..31).  With sM == 1 and 16-byte
+ *   aligned rows the lags come from the matrix cores (fp16 operands, fp32 accumulation, <= 1e-4 abs vs float64);
+ *   any other layout takes the fp32 FFT kernel. */
 int seld_gcc_phat(const float* spec_complex, int64_t N, int64_t C, int64_t F, float* out, int64_t sN, int64_t sC,
                   int64_t sM, int64_t sT, void* stream);
 
