@@ -149,19 +149,25 @@ __global__ __launch_bounds__(kGlueThreads) void column_partials_kernel(const voi
   }
 }
 
-// out[n] = sum over the row blocks of partial[y][n] (fixed order): stage 2.  256 threads = 64 columns x 4 row slots.
+// out[n] = sum over the row blocks of partial[y][n] (fixed order): stage 2.  256 threads = 16 columns x 16 row slots
+// (narrow blocks: a 256-column matrix still gives 16 workgroups, and a thread adds at most 8 partial rows).
 __global__ __launch_bounds__(kGlueThreads) void column_finish_kernel(const float* __restrict__ partial, int blocks, int n_cols,
                                                                      void* __restrict__ out, int out_bf16) {
-  __shared__ float red[4][64];
+  __shared__ float red[16][17];
   const int tid = threadIdx.x;
-  const int c = tid & 63, slot = tid >> 6;
-  const int col = blockIdx.x * 64 + c;
+  const int c = tid & 15, slot = tid >> 4;
+  const int col = blockIdx.x * 16 + c;
   float sum = 0.0f;
   if (col < n_cols)
-    for (int y = slot; y < blocks; y += 4) sum += partial[static_cast<long>(y) * n_cols + col];
+    for (int y = slot; y < blocks; y += 16) sum += partial[static_cast<long>(y) * n_cols + col];
   red[slot][c] = sum;
   __syncthreads();
-  if (slot == 0 && col < n_cols) store_from_float(out, col, out_bf16 != 0, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+  if (slot == 0 && col < n_cols) {
+    float total = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) total += red[k][c];
+    store_from_float(out, col, out_bf16 != 0, total);
+  }
 }
 
 // dW_hh[d][g][u][k] from the two wasteful-but-well-shaped products the host forms (seld_gru._BiGRULayer.backward):
@@ -258,9 +264,9 @@ int seld_sum_chunks(const void* partial, int in_is_bf16, int64_t chunks, int64_t
 
 int64_t seld_column_sums_blocks(int64_t rows, int64_t n_cols) {
   const long col_blocks = (n_cols + 255) / 256;
-  long rb = 1024 / col_blocks;
+  long rb = 2048 / col_blocks;
   if (rb < 8) rb = 8;
-  if (rb > 64) rb = 64;
+  if (rb > 128) rb = 128;
   if (rb > rows) rb = rows;
   return rb;
 }
@@ -278,7 +284,7 @@ int seld_column_sums(const void* g, int in_is_bf16, int64_t rows, int64_t n_cols
   hipLaunchKernelGGL(column_partials_kernel, dim3(static_cast<unsigned>((n_cols + 255) / 256), static_cast<unsigned>(rb)),
                      dim3(kGlueThreads), 0, stream, g, in_is_bf16, static_cast<long>(rows), static_cast<int>(n_cols),
                      static_cast<int>(rows_per_block), partial);
-  hipLaunchKernelGGL(column_finish_kernel, dim3(static_cast<unsigned>((n_cols + 63) / 64)), dim3(kGlueThreads), 0, stream,
+  hipLaunchKernelGGL(column_finish_kernel, dim3(static_cast<unsigned>((n_cols + 15) / 16)), dim3(kGlueThreads), 0, stream,
                      partial, static_cast<int>(rb), static_cast<int>(n_cols), out, out_is_bf16);
   SELD_HIP_TRY(hipGetLastError());
   return kOk;
