@@ -462,6 +462,17 @@ static int tail_check(const char* who, int64_t rows, int C, int pool) {
   return kOk;
 }
 
+// Partial-sum rows of a statistics / reduction pass: every thread should have >= 8 rows to add, at most kTailStatBlocks
+// workgroups.  (A fixed 1024 made the finalise kernels of the ResNet's small late-stage activations -- 53 BatchNorm
+// layers per iteration -- add 1024 partial rows of a tensor with 2048 rows.)
+static int tail_stat_blocks(long work_rows, int C) {
+  const long per_block = kTailThreads / (C / 8);
+  long blocks = (work_rows + per_block * 8 - 1) / (per_block * 8);
+  if (blocks < 32) blocks = 32;
+  if (blocks > kTailStatBlocks) blocks = kTailStatBlocks;
+  return static_cast<int>(blocks);
+}
+
 static unsigned tail_grid(const DeviceState* st, long work_rows, int C) {
   const long per_block = kTailThreads / (C / 8);
   long blocks = (work_rows + per_block - 1) / per_block;
@@ -491,7 +502,7 @@ int seld_conv_tail_forward(const void* x, const void* residual, int is_bf16, int
   if (!training && (!running_mean || !running_var))
     return fail(kErrInvalidArgument, "seld_conv_tail_forward: eval mode needs the running statistics");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const int nblocks = kTailStatBlocks;
+  const int nblocks = tail_stat_blocks(rows, C);
   if (training) {
     if (is_bf16) hipLaunchKernelGGL(tail_stats_kernel<__hip_bfloat16>, dim3(nblocks), dim3(kTailThreads), 0, stream, x,
                                     static_cast<long>(rows), C, workspace);
@@ -539,9 +550,9 @@ int seld_conv_tail_backward(const void* x, const void* residual, const void* dy,
   if (!x || !dy || !dx || !mean_invstd || !scale_shift || !dweight || !dbias || !workspace)
     return fail(kErrInvalidArgument, "seld_conv_tail_backward: null pointer");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const int nblocks = kTailStatBlocks;
   const long out_rows = pool == 2 ? rows / 2 : rows;
-  float* coef = workspace + 2L * nblocks * C;        // [2][C] after the partial sums
+  const int nblocks = tail_stat_blocks(out_rows, C);
+  float* coef = workspace + 2L * kTailStatBlocks * C;        // [2][C] after the (at most kTailStatBlocks) partial sums
 #define SELD_TAIL_BWD(T, P)                                                                                      \
   do {                                                                                                           \
     hipLaunchKernelGGL((tail_bwd_reduce_kernel<T, P>), dim3(nblocks), dim3(kTailThreads), 0, stream, x, residual, \
