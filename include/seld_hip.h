@@ -96,6 +96,12 @@ int seld_foa_intensity(const float* spec_complex, int64_t N, int64_t F, float* o
 int seld_gcc_phat(const float* spec_complex, int64_t N, int64_t C, int64_t F, float* out, int64_t sN, int64_t sC,
                   int64_t sM, int64_t sT, void* stream);
 
+/* Host copy of the matrix-core kernel's constant operand -- no GPU needed (used by the CPU tests): 2 x 3 x 16 fragments of
+ * 64 lanes x 8 IEEE binary16 values = 49 152 halves; fragment (part, tile, kstep), lane l, element j holds, for bin
+ * k = 32 kstep + 8 (l >> 4) + j and lag n = 16 tile + (l & 15):  part 0: w_k cos(2 pi k n / 960),  part 1: -w_k sin(...),
+ * w_0 = w_480 = 1, else 2; zero for k > 480 or n > 32. */
+int seld_gcc_table_host(uint16_t* table);
+
 /* ---- labels: dataset.py:60-119 metadata_to_labels + utils.py:77-90 polar_to_grid ---------- */
 /* events: int32 [R][5] = (meta_frame, class, source, azimuth_deg, elevation_deg), the CSV rows after
  * the reference's int() casts (dataset.py:93-97).  T = int((L/sr*1000)/20) label frames, computed by

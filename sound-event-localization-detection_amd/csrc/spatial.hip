@@ -22,6 +22,8 @@
 
 #include "seld_common.h"
 
+extern "C" int seld_gcc_table_host(uint16_t* table);      // include/seld_hip.h (defined below)
+
 namespace seld {
 
 constexpr int kIvPitch = 512;                       // floats per intensity row in LDS (481 used, rest zero)
@@ -635,13 +637,7 @@ static unsigned short half_bits(float v) {
 int build_gcc_table(DeviceState* st) {
   if (st->gcc_table) return kOk;
   std::vector<unsigned short> host(kGmTableBytes / 2);
-  for (int part = 0; part < 2; ++part)
-    for (int tile = 0; tile < kGmLagTiles; ++tile)
-      for (int ks = 0; ks < kGmKSteps; ++ks)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int j = 0; j < 8; ++j)
-            host[((((part * kGmLagTiles + tile) * kGmKSteps + ks) * 64) + lane) * 8 + j] =
-                half_bits(static_cast<float>(gcc_table_value(part, tile, ks, lane, j)));
+  if (int rc = seld_gcc_table_host(host.data())) return rc;
   SELD_HIP_TRY(hipMalloc(&st->gcc_table, kGmTableBytes));
   SELD_HIP_TRY(hipMemcpy(st->gcc_table, host.data(), kGmTableBytes, hipMemcpyHostToDevice));
   return kOk;
@@ -665,6 +661,19 @@ int seld_foa_intensity(const float* spec_complex, int64_t N, int64_t F, float* o
   hipLaunchKernelGGL(foa_iv_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kIvWaves * 64),
                      kIvWaves * kIvLdsFloatsPerWave * sizeof(float), static_cast<hipStream_t>(stream_), a);
   SELD_HIP_TRY(hipGetLastError());
+  return kOk;
+}
+
+int seld_gcc_table_host(uint16_t* table) {
+  using namespace seld;
+  if (!table) return fail(kErrInvalidArgument, "seld_gcc_table_host: null pointer");
+  for (int part = 0; part < 2; ++part)
+    for (int tile = 0; tile < kGmLagTiles; ++tile)
+      for (int ks = 0; ks < kGmKSteps; ++ks)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j)
+            table[((((part * kGmLagTiles + tile) * kGmKSteps + ks) * 64) + lane) * 8 + j] =
+                half_bits(static_cast<float>(gcc_table_value(part, tile, ks, lane, j)));
   return kOk;
 }
 

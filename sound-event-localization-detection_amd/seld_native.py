@@ -57,6 +57,7 @@ def _declare(lib):
     for fn in (lib.seld_logmel_spectrum_f32, lib.seld_logmel_spectrum_i16):
         fn.argtypes = [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr]
         fn.restype = ctypes.c_int
+    lib.seld_gcc_table_host.argtypes = [_ptr]
     lib.seld_gcc_phat.argtypes = [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr]
     lib.seld_labels_rasterise.argtypes = [_ptr, _i64, _i64, _int, _int, _ptr, _ptr]
     lib.seld_labels_expand.argtypes = [_ptr, _i64, _int, _ptr, _ptr]

@@ -158,3 +158,34 @@ def test_device_code_has_no_vcc_scc_select_miscompile(tmp_path):
             wide_cmp = [x for x in lines[j + 1:i] if "v_cmp" in x and "64" in x]
             assert not (wide_cmp and writer.startswith(("s_sub", "s_add", "s_lsh"))), \
                 f"{src.name}: '{line.strip()}' selects on the SCC of '{writer}' after '{wide_cmp[0].strip()}'"
+
+
+def test_gcc_table_reproduces_irfft_lags():
+    """The constant operand of the matrix-core GCC-PHAT kernel (csrc/spatial.hip, seld_gcc_table_host: fp16 cosine / sine
+    fragments) and the way the kernel combines its two products -- cc[+l] = (C[l] + S[l]) / 960, cc[-l] = (C[l] - S[l]) /
+    960 -- against numpy's irfft of random unit phase factors; the fragment layout is the one the kernel indexes."""
+    import ctypes
+    import numpy as np
+    import seld_native
+    lib = seld_native.load_library()
+    halves = np.zeros(2 * 3 * 16 * 64 * 8, dtype=np.uint16)
+    assert lib.seld_gcc_table_host(halves.ctypes.data_as(ctypes.c_void_p)) == 0
+    frag = halves.view(np.float16).astype(np.float64).reshape(2, 3, 16, 64, 8)      # [part][tile][kstep][lane][j]
+    table = np.zeros((2, 48, 512))                                                   # [part][lag][bin]
+    for tile in range(3):
+        for ks in range(16):
+            for lane in range(64):
+                table[:, 16 * tile + (lane & 15), 32 * ks + 8 * (lane >> 4):32 * ks + 8 * (lane >> 4) + 8] = \
+                    frag[:, tile, ks, lane, :]
+    assert not table[:, 33:, :].any() and not table[:, :, 481:].any()               # padding lags / bins are zero
+    rng = np.random.default_rng(5)
+    phase = np.exp(1j * rng.uniform(-np.pi, np.pi, size=(7, 481)))
+    cc = np.fft.irfft(phase, n=960, axis=1)                                          # [7, 960]
+    c = phase.real @ table[0, :, :481].T                                             # [7, 48]
+    s = phase.imag @ table[1, :, :481].T
+    plus = (c + s) / 960.0
+    minus = (c - s) / 960.0
+    for lag in range(0, 32):
+        assert np.abs(plus[:, lag] - cc[:, lag]).max() <= 2e-5
+    for lag in range(1, 33):
+        assert np.abs(minus[:, lag] - cc[:, 960 - lag]).max() <= 2e-5
