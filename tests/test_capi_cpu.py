@@ -189,3 +189,16 @@ def test_gcc_table_reproduces_irfft_lags():
         assert np.abs(plus[:, lag] - cc[:, lag]).max() <= 2e-5
     for lag in range(1, 33):
         assert np.abs(minus[:, lag] - cc[:, 960 - lag]).max() <= 2e-5
+    # the kernel's rounding points on top of the table's: the phase factors are formed in fp32 and rounded to fp16 once,
+    # products accumulated in fp32.  2000 random rows x 64 lags stay well inside the 1e-4 the GPU tests hold the kernel to.
+    phase = np.exp(1j * rng.uniform(-np.pi, np.pi, size=(2000, 481)))
+    cc = np.fft.irfft(phase, n=960, axis=1)
+    re16 = phase.real.astype(np.float32).astype(np.float16).astype(np.float32)
+    im16 = phase.imag.astype(np.float32).astype(np.float16).astype(np.float32)
+    c = (re16 @ table[0, :, :481].T.astype(np.float32)).astype(np.float64)
+    s = (im16 @ table[1, :, :481].T.astype(np.float32)).astype(np.float64)
+    got = np.concatenate([((c - s) / 960.0)[:, 32:0:-1], ((c + s) / 960.0)[:, 0:32]], axis=1)      # lags -32..31
+    ref = np.concatenate([cc[:, 928:960], cc[:, 0:32]], axis=1)
+    err = np.abs(got - ref)
+    assert err.max() <= 6e-5, err.max()
+    assert np.sqrt((err ** 2).mean()) <= 1.5e-5
