@@ -93,6 +93,13 @@ def parse_args():
                     help="feature set (logmel = the reference; logmel_gcc with --channels 8 = BASELINE configs[3]'s "
                          "per-GPU shard: 8-ch MIC, 8 log-mel + 28 GCC-PHAT input channels)")
     ap.add_argument("--channels", type=int, default=4, help="audio channels of the synthetic clips")
+    ap.add_argument("--loss", default="class", choices=["class", "three_term"],
+                    help="class = the modular loss.py (class MSE); three_term = MSE + AIUR + CL on probabilities "
+                         "(smrl_seld_gaussian.py:946-1072, BASELINE configs[4])")
+    ap.add_argument("--gaussian-augment", action="store_true",
+                    help="labels by the Gaussian box rasteriser (smrl_seld_gaussian.py:397-534, BASELINE configs[4])")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the short runs of the other BASELINE workloads after the timed region (`other_workloads`)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N ranks share the visible GPU(s) over gloo (DDP rehearsal on a one-GPU box; not a measurement)")
     return ap.parse_args()
@@ -185,10 +192,19 @@ class HotPath:
         self.model = trainer.broadcast_replica_state(model, world) if graphed else trainer.wrap_ddp(model, device, world)
         weights = torch.ones(14, device=device)
         weights[13] = 0.05
-        self.criterion = trainer.SMRSELDLoss(loss_type="mse", w_class=1.0, grid_size=(18, 36), class_weights=weights)
+        self.three_term = getattr(args, "loss", "class") == "three_term"
+        self.criterion = trainer.SMRSELDLoss(loss_type="mse", w_class=1.0, w_aiur=1.0, w_cl=1.0, grid_size=(18, 36),
+                                             class_weights=weights, three_term=self.three_term)
         self.optimizer = trainer.make_optimizer(self.model, cfg.LEARNING_RATE, device, capturable=graphed)
         self.stepper = trainer.make_stepper(self.model, self.criterion, self.optimizer, device, world)
         self.pcm, self.events = synth_clip_batch(rank, device, args.channels)
+        self.centres = None
+        if getattr(args, "gaussian_augment", False):
+            # one normal draw per (class, source) of every clip, seeded (the reference draws them when it builds the
+            # dataset, smrl_seld_gaussian.py:426-437); the box rasteriser itself runs in every step
+            rng = np.random.default_rng(4321 + rank)
+            self.centres = [torch.from_numpy(seld_native.gaussian_source_noise(ev.cpu().numpy(), rng=rng)).to(device)
+                            for ev in self.events]
         total = CLIPS_PER_STEP * FRAMES_PER_CLIP
         self.starts = torch.arange(0, total, HOP, dtype=torch.int64, device=device)          # 480 windows
         self.spec_full = torch.empty(CLIPS_PER_STEP, 1 + CLIP_SAMPLES // 480, self.feature_channels, 64, device=device)
@@ -210,8 +226,12 @@ class HotPath:
             e1.record()
             self.feat_events.append((e0, e1))
         for i, ev in enumerate(self.events):
-            nat.rasterise_labels(ev, FRAMES_PER_CLIP, device=dev,
-                                 out=self.mask_tm[i * FRAMES_PER_CLIP:(i + 1) * FRAMES_PER_CLIP])
+            if self.centres is not None:
+                self.mask_tm[i * FRAMES_PER_CLIP:(i + 1) * FRAMES_PER_CLIP] = \
+                    nat.rasterise_labels_gaussian(ev, self.centres[i], FRAMES_PER_CLIP, device=dev)
+            else:
+                nat.rasterise_labels(ev, FRAMES_PER_CLIP, device=dev,
+                                     out=self.mask_tm[i * FRAMES_PER_CLIP:(i + 1) * FRAMES_PER_CLIP])
         spec_tm = self.spec_full[:, :FRAMES_PER_CLIP].reshape(-1, self.feature_channels, 64)   # crop + concatenate
         if timed:
             m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -398,6 +418,97 @@ def cpu_baseline():
     }
 
 
+def overlap_windows(hot, device, iterations=20):
+    """The data-parallel step's backward stages on ONE rank, without collectives (seld_graph.GraphedTrainStep(split=True):
+    exactly the graphs the N-rank path replays): average duration of every replayed graph, measured with HIP events
+    between the replays, after the timed region.  The window that hides the all-reduce of bucket k is everything replayed
+    after stage k and before the update graph."""
+    import seld_graph
+    trainer = hot.trainer
+    step = seld_graph.GraphedTrainStep(hot.model, hot.criterion, hot.optimizer, device, world=1,
+                                       autocast=lambda: trainer.autocast_context(device), split=True)
+    nat = hot.native
+    spec_tm = hot.spec_full[:, :FRAMES_PER_CLIP].reshape(-1, hot.feature_channels, 64)
+    starts = hot.starts[:BATCH]
+    spec = nat.gather_windows(spec_tm, starts, WINDOW)
+    mask = nat.gather_windows(hot.mask_tm, starts, WINDOW)
+    for _ in range(seld_graph.WARMUP + 2):
+        step(spec, mask)
+    step.timing = True
+    for _ in range(iterations):
+        step(spec, mask)
+    seg = step.segment_ms()
+    stats = step.stats()
+    step.close()
+    if not seg or stats.get("capture_error"):
+        return {"error": stats.get("capture_error") or "no staged graphs"}
+    stages, update = seg[:-1], seg[-1]
+    buckets = stats["gradient_buckets"]
+    return {"measured": f"1 GPU, {iterations} replays of the staged graphs without collectives, HIP events between replays",
+            "backward_stages": len(stages), "stage_ms": stages, "update_ms": update,
+            "iteration_ms": sum(seg),
+            "buckets": [{"stage": b["stage"], "bytes": b["bytes"],
+                         "hidden_under_ms": sum(stages[b["stage"] + 1:])} for b in buckets],
+            "reduce_dtype": stats["reduce_dtype"]}
+
+
+OTHER_WORKLOADS = (
+    ("conformer", dict(model="conformer")),
+    ("resnet_conformer + three-term loss + Gaussian label augmentation",
+     dict(model="resnet_conformer", loss="three_term", gaussian_augment=True)),
+    ("crnn, 8-ch MIC array, log-mel + GCC-PHAT (36 input channels)", dict(model="crnn", features="logmel_gcc", channels=8)),
+)
+
+
+def other_workloads(args, device, steps=3, warmup=2):
+    """Short runs (``warmup`` + ``steps`` steps of 32 clips each) of the other BASELINE.json workloads in this process,
+    after the headline's timed region: configs[2] (Conformer), configs[4]'s model + loss + augmentation on one GPU,
+    configs[3]'s per-GPU shard.  Reported beside the headline, never part of ``value``."""
+    import copy
+    import gc
+    out = []
+    for name, override in OTHER_WORKLOADS:
+        a = copy.copy(args)
+        for k, v in override.items():
+            setattr(a, k, v)
+        try:
+            hot = HotPath(a, device, 0, 1)
+            for _ in range(warmup):
+                hot.step(timed=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = hot.step(timed=True)
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            feat_ms = float(np.mean([x.elapsed_time(y) for x, y in hot.feat_events]))
+            model_ms = float(np.mean([x.elapsed_time(y) for x, y in hot.model_events]))
+            windows = CLIPS_PER_STEP * FRAMES_PER_CLIP // HOP
+            tflops = windows * GFLOP_PER_WINDOW[a.model] / (model_ms * 1e-3) / 1e3
+            frames = 1 + CLIP_SAMPLES // 480
+            feat_bytes = CLIPS_PER_STEP * (a.channels * CLIP_SAMPLES * 4 + hot.feature_channels * 64 * frames * 4)
+            out.append({"workload": f"{name}, bs={BATCH} windows, bf16, 1 GPU", "baseline_config": WORKLOAD_CONFIG[name],
+                        "clips_per_s": CLIPS_PER_STEP * steps / elapsed, "steps": steps, "warmup": warmup,
+                        "ms_per_iteration": model_ms / (windows // BATCH),
+                        "roofline_model_frac": tflops / MFMA_BF16_PEAK_TFLOPS, "model_tflops": tflops,
+                        "feature_phase_ms": feat_ms, "feature_hbm_frac": feat_bytes / (feat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "final_loss": float(loss.item()),
+                        "captured_step": hot.stepper.stats() if hasattr(hot.stepper, "stats") else None})
+            if hasattr(hot.stepper, "close"):
+                hot.stepper.close()
+        except Exception as exc:           # noqa: BLE001  -- a secondary workload must not take the headline line down
+            out.append({"workload": name, "error": f"{type(exc).__name__}: {exc}"})
+        hot = None
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
+WORKLOAD_CONFIG = {OTHER_WORKLOADS[0][0]: "BASELINE configs[2]",
+                   OTHER_WORKLOADS[1][0]: "BASELINE configs[4] (model, loss and augmentation; one GPU of the 8)",
+                   OTHER_WORKLOADS[2][0]: "BASELINE configs[3] (the per-GPU shard: 32 of the 256 windows)"}
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -496,13 +607,15 @@ def main():
                        "optimizer_iterations_per_step": windows_per_step // BATCH,
                        "parallelism": f"dp{world}", "windows_per_s": clips * 60 / elapsed,
                        "final_loss": float(loss.item())},
-            "roofline": {"kernel": "seld::logmel_main_kernel<float> + logmel_edge_kernel<float> (fused STFT+mel+dB)"
+            "roofline": {"kernel": "seld::logmel_main_kernel<float, false> (fused STFT+mel+dB; the edge iterations are its "
+                                   "trailing workgroups)"
                          if args.features == "logmel" else f"feature phase: seld::logmel_main_kernel<float, true> (log-mel + spectra) + {'seld::gcc_mfma_kernel' if args.features == 'logmel_gcc' else 'seld::foa_iv_kernel'}",
                          "bound": "hbm",
                          "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": traffic[1] * CLIPS_PER_STEP if traffic and args.features == "logmel" and args.channels == 4 else None,
-                         "traffic_source": f"profiles/{traffic[0]} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+                         "traffic_source": f"committed PMC pass profiles/{traffic[0]}, not this run (rocprofv3 --pmc "
+                                           f"FETCH_SIZE x2 + WRITE_SIZE per launch)"
                          if traffic and args.features == "logmel" and args.channels == 4 else None,
                          "bytes_per_launch": CLIPS_PER_STEP * bytes_per_clip, "avg_launch_ms": feat_ms,
                          "features_only_clips_per_s": CLIPS_PER_STEP / (feat_ms * 1e-3)},
@@ -518,7 +631,12 @@ def main():
             line["config"]["per_rank_clips_per_s"] = [CLIPS_PER_STEP * args.steps / t for t in per_rank]
             if backend != "nccl":
                 line["rehearsal"] = True          # ranks share a GPU over gloo: a functional check, not a measurement
-        line["config"]["captured_step"] = hot.stepper.stats() if hasattr(hot.stepper, "stats") else None
+        step_stats = hot.stepper.stats() if hasattr(hot.stepper, "stats") else None
+        line["config"]["captured_step"] = step_stats
+        if world > 1:
+            # the gradient exchange of this run: buckets all-reduced asynchronously between the backward-stage graphs
+            line["allreduce_overlap"] = bool(step_stats and step_stats.get("allreduce_overlap"))
+            line["gradient_buckets"] = (step_stats or {}).get("gradient_buckets")
         if getattr(hot, "loss_trace", None):
             line["config"]["loss_trace"] = hot.loss_trace
         if hasattr(hot.optimizer, "fused_casts"):
@@ -526,6 +644,15 @@ def main():
                                                 "per_tensor_fallbacks": hot.optimizer.fallback_casts}
         if world == 1 and not args.no_kernel_rooflines:
             line["kernels"] = kernel_rooflines(device)
+            if hasattr(hot.stepper, "stats"):
+                line["allreduce_overlap"] = overlap_windows(hot, device)
+        if world == 1 and not args.no_other_workloads and args.model == "crnn" and args.features == "logmel" \
+                and args.loss == "class" and not args.fp32:
+            if hasattr(hot.stepper, "close"):
+                hot.stepper.close()
+            hot.pcm = hot.spec_full = hot.mask_tm = None
+            torch.cuda.empty_cache()
+            line["other_workloads"] = other_workloads(args, device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -107,6 +107,12 @@ class Config:
     GRAPH_STEP = True           # one optimiser iteration = one replayed HIP graph per input shape (seld_graph.py): the eager
                                 # loop spends ~3.5 ms of host time enqueueing ~300 launches per CRNN iteration; data
                                 # parallel: graph (forward + backward) -> flat all-reduce -> graph (Adam)
+    OVERLAP_ALLREDUCE = True    # data parallel + GRAPH_STEP: the backward pass is cut at the models' seld_cut.boundary points and
+                                # captured as one graph per stage; the gradients a stage completes are all-reduced (RCCL,
+                                # asynchronously) while the next stages run.  False: one graph, then one blocking exchange
+    GRAD_REDUCE_DTYPE = "param"  # wire dtype of that exchange: "param" = the bf16 working-weight gradients are summed in bf16
+                                # (half the xGMI bytes), "fp32" = cast into fp32 buffers first (what an autocast port of the
+                                # reference would reduce; the buffers double as the fp32 masters' gradients)
     TUNED_GEMMS = True          # apply tuned/gemm_gfx950.csv: hipBLASLt / rocBLAS kernel selections for the models' GEMM
                                 # shapes, timed offline on an MI355X (seld_tuned.py; ignored on any other library stack)
     DDP_BUCKET_MB = 8           # RCCL all-reduce bucket size: with bf16 working weights the CRNN's gradients are 22 MB, so

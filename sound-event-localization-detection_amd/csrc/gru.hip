@@ -200,7 +200,7 @@ struct GruFwdArgs {
 // The MFMA computes gh^T = W_hh h^T: M = gate rows (units), N = sequence columns; D[m = 4q+i][n = c].  The step
 // body has NO divergent control flow (batch padded to whole tiles by the host; kSave compile time): the compiler
 // counts outstanding loads / stores exactly and never drains the queue.
-template <typename T, bool kSave, int kOrder>
+template <typename T, bool kSave>
 __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* wn_lds, __hip_bfloat16* hbuf,
                                                   const bf16x8 (&wr)[2][8], const bf16x8 (&wz)[2][8]) {
   typedef typename Types<T>::Data D;
@@ -264,84 +264,35 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
     const __hip_bfloat16* hrow = hbuf + (cur * kSeqs + seq) * kHPitch + 8 * q;
     const bf16x8* wnp = wn_lds + wave * 2 * 8 * 64 + lane;
     float ghr[kU], ghz[kU], gg[kU], rr[kU], zz[kU], nn[kU], hh[kU];
-    if (kOrder == 0) {
-      bf16x8 hfrag = *reinterpret_cast<const bf16x8*>(hrow);
-      bf16x8 wn0 = wnp[0], wn1 = wnp[8 * 64];
+    bf16x8 hfrag = *reinterpret_cast<const bf16x8*>(hrow);
+    bf16x8 wn0 = wnp[0], wn1 = wnp[8 * 64];
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        bf16x8 hfrag_n = hfrag, wn0_n = wn0, wn1_n = wn1;
-        if (kk + 1 < 8) {
-          hfrag_n = *reinterpret_cast<const bf16x8*>(hrow + 32 * (kk + 1));
-          wn0_n = wnp[(kk + 1) * 64];
-          wn1_n = wnp[(8 + kk + 1) * 64];
-        }
-        acc_r[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[0][kk], hfrag, acc_r[0], 0, 0, 0);
-        acc_z[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wz[0][kk], hfrag, acc_z[0], 0, 0, 0);
-        acc_n[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn0, hfrag, acc_n[0], 0, 0, 0);
-        acc_r[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[1][kk], hfrag, acc_r[1], 0, 0, 0);
-        acc_z[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wz[1][kk], hfrag, acc_z[1], 0, 0, 0);
-        acc_n[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn1, hfrag, acc_n[1], 0, 0, 0);
-        hfrag = hfrag_n;
-        wn0 = wn0_n;
-        wn1 = wn1_n;
+    for (int kk = 0; kk < 8; ++kk) {
+      bf16x8 hfrag_n = hfrag, wn0_n = wn0, wn1_n = wn1;
+      if (kk + 1 < 8) {
+        hfrag_n = *reinterpret_cast<const bf16x8*>(hrow + 32 * (kk + 1));
+        wn0_n = wnp[(kk + 1) * 64];
+        wn1_n = wnp[(8 + kk + 1) * 64];
       }
-      // ---- gates for this lane's (sequence, kU units)
-      own_values(acc_r, ghr);
-      own_values(acc_z, ghz);
-      own_values(acc_n, gg);
+      acc_r[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[0][kk], hfrag, acc_r[0], 0, 0, 0);
+      acc_z[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wz[0][kk], hfrag, acc_z[0], 0, 0, 0);
+      acc_n[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn0, hfrag, acc_n[0], 0, 0, 0);
+      acc_r[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[1][kk], hfrag, acc_r[1], 0, 0, 0);
+      acc_z[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wz[1][kk], hfrag, acc_z[1], 0, 0, 0);
+      acc_n[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn1, hfrag, acc_n[1], 0, 0, 0);
+      hfrag = hfrag_n;
+      wn0 = wn0_n;
+      wn1 = wn1_n;
+    }
+    // ---- gates for this lane's (sequence, kU units)
+    own_values(acc_r, ghr);
+    own_values(acc_z, ghz);
+    own_values(acc_n, gg);
 #pragma unroll
-      for (int i = 0; i < kU; ++i) {
-        gg[i] += bias_n[i];
-        rr[i] = sigmoid_f(gir[i] + ghr[i]);
-        zz[i] = sigmoid_f(giz[i] + ghz[i]);
-      }
-    } else {
-      // ---- gate-major: all of r, then z, then n.  A 16x16x32 MFMA holds the SIMD's vector issue for 8 of its 16
-      // cycles: the redistribution + sigmoid of a finished gate issues in the gaps of the next gate's MFMAs (this
-      // wavefront's and the co-resident one's) instead of after all 48; only the n gate's tanh and the state
-      // update remain behind the last MFMA.  The 8 B fragments of h are read once and kept (32 VGPRs).
-      // The B fragments of h are re-read from LDS for every gate (16 B per lane and k-step, one k-step ahead: keeping
-      // all 8 would cost 32 registers the kernel does not have).
-      auto hread = [&](int kk) { return *reinterpret_cast<const bf16x8*>(hrow + 32 * (kk & 7)); };
-      bf16x8 hfrag = hread(0);
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        const bf16x8 hnext = hread(kk + 1);
-        acc_r[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[0][kk], hfrag, acc_r[0], 0, 0, 0);
-        acc_r[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[1][kk], hfrag, acc_r[1], 0, 0, 0);
-        hfrag = hnext;
-      }
-      own_values(acc_r, ghr);
-#pragma unroll
-      for (int i = 0; i < kU; ++i) rr[i] = sigmoid_f(gir[i] + ghr[i]);
-      bf16x8 wn0 = wnp[0], wn1 = wnp[8 * 64];
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        const bf16x8 hnext = hread(kk + 1);
-        acc_z[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wz[0][kk], hfrag, acc_z[0], 0, 0, 0);
-        acc_z[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wz[1][kk], hfrag, acc_z[1], 0, 0, 0);
-        hfrag = hnext;
-      }
-      own_values(acc_z, ghz);
-#pragma unroll
-      for (int i = 0; i < kU; ++i) zz[i] = sigmoid_f(giz[i] + ghz[i]);
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        bf16x8 hnext = hfrag, wn0_n = wn0, wn1_n = wn1;
-        if (kk + 1 < 8) {
-          hnext = hread(kk + 1);
-          wn0_n = wnp[(kk + 1) * 64];
-          wn1_n = wnp[(8 + kk + 1) * 64];
-        }
-        acc_n[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn0, hfrag, acc_n[0], 0, 0, 0);
-        acc_n[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn1, hfrag, acc_n[1], 0, 0, 0);
-        hfrag = hnext;
-        wn0 = wn0_n;
-        wn1 = wn1_n;
-      }
-      own_values(acc_n, gg);
-#pragma unroll
-      for (int i = 0; i < kU; ++i) gg[i] += bias_n[i];
+    for (int i = 0; i < kU; ++i) {
+      gg[i] += bias_n[i];
+      rr[i] = sigmoid_f(gir[i] + ghr[i]);
+      zz[i] = sigmoid_f(giz[i] + ghz[i]);
     }
 #pragma unroll
     for (int i = 0; i < kU; ++i) {
@@ -383,7 +334,7 @@ __device__ __forceinline__ void gru_forward_steps(const GruFwdArgs& a, bf16x8* w
   if (t < a.T) step(t, g_b);
 }
 
-template <typename T, int kOrder>
+template <typename T>
 __global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16x8* wn_lds = reinterpret_cast<bf16x8*>(smem);
@@ -407,181 +358,10 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_forward_kernel(GruFwdArgs 
           *reinterpret_cast<const bf16x8*>(w + static_cast<long>(2 * kH + unit) * kH + k0);
     }
   }
-#ifdef SELD_GRU_SKEW
-  if (wave < 4) __builtin_amdgcn_s_setprio(SELD_GRU_SKEW);   // experiment: de-phase the two waves of a SIMD
-#endif
   for (int i = tid; i < 2 * kSeqs * kHPitch; i += kGruThreads) hbuf[i] = __float2bfloat16(0.0f);   // h_0 = 0
   __syncthreads();
-  if (a.saved) gru_forward_steps<T, true, kOrder>(a, wn_lds, hbuf, wr, wz);
-  else gru_forward_steps<T, false, kOrder>(a, wn_lds, hbuf, wr, wz);
-}
-
-// ---- 4-wavefront variant: ALL of W_hh in registers ------------------------------------------------------------------
-// One wavefront per SIMD owns the whole 512-entry register file (256 VGPRs + 256 AGPRs; MFMA A / B operands may live
-// in either half): the 96 A fragments of its 64 hidden units x 3 gates are 384 registers, so nothing of W_hh is read
-// from LDS during the recurrence (the 8-wavefront kernel re-reads 128 KB of n-gate weights per step).  A physical
-// wavefront does the work of two "logical" wavefronts of the tile layout (w = 2 p, 2 p + 1) one after the other: the
-// gate math of the first half has no dependence on the MFMAs of the second, so the scheduler can issue it in the
-// MFMAs' shadow (an MFMA holds the SIMD's issue port for 8 of its 16 cycles).
-// RESULT (kept as an experiment behind SELD_GRU_FORWARD=4, not the default): hipcc issues the two halves strictly one
-// after the other (MFMAs, gate math, MFMAs, gate math -- the asm MFMAs are opaque to sched_group_barrier) and the
-// kernel is 36 % SLOWER than the 8-wavefront one, see seld_gru_forward.
-constexpr int kGru4Threads = 256;
-
-template <typename T, bool kSave>
-__device__ __forceinline__ void gru_forward4_steps(const GruFwdArgs& a, __hip_bfloat16* hbuf,
-                                                   const bf16x8 (&w)[2][3][2][8]) {
-  typedef typename Types<T>::Data D;
-  typedef typename Types<T>::Saved S;
-  constexpr bool kLdsY = sizeof(T) == 2;
-  const int tid = threadIdx.x;
-  const int pwave = tid >> 6, lane = tid & 63;
-  const int q = lane >> 4, c = lane & 15;
-  const int seq = c % kSeqs;
-  const int dir = blockIdx.y;
-  const long tile = blockIdx.x;
-  const float* bh = a.b_hn + dir * kH;
-  const Group<D>* gi = static_cast<const Group<D>*>(a.gi);
-  T* y = static_cast<T*>(a.y);
-  PairOf<S>* saved = static_cast<PairOf<S>*>(a.saved);
-  const long b = tile * kSeqs + seq;
-  int unit0[2];
-  float bias_n[2][kU], h_prev[2][kU];
-#pragma unroll
-  for (int l = 0; l < 2; ++l) {
-    unit0[l] = lane_unit0(2 * pwave + l, lane);
-#pragma unroll
-    for (int i = 0; i < kU; ++i) {
-      bias_n[l][i] = bh[unit0[l] + i];
-      h_prev[l][i] = 0.0f;
-    }
-  }
-  auto time_of = [&](long step) { return dir == 0 ? step : a.T - 1 - step; };
-  const long b_read = b < a.B ? b : a.B - 1;
-  auto load_gi = [&](long step, Group<D> (&g)[2][3]) {
-    const Group<D>* p = gi + (((b_read * a.T + time_of(step)) * 2 + dir) * 3 * kH) / kU;
-#pragma unroll
-    for (int l = 0; l < 2; ++l)
-#pragma unroll
-      for (int gate = 0; gate < 3; ++gate) g[l][gate] = p[(gate * kH + unit0[l]) / kU];
-  };
-
-  auto step = [&](long t, Group<D> (&g)[2][3]) {
-    const long tt = time_of(t);
-    const int cur = static_cast<int>(t & 1), nxt = cur ^ 1;
-    float gir[2][kU], giz[2][kU], gin[2][kU];
-#pragma unroll
-    for (int l = 0; l < 2; ++l) {
-      dec1<D>(g[l][0], gir[l]);
-      dec1<D>(g[l][1], giz[l]);
-      dec1<D>(g[l][2], gin[l]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    load_gi(t + 2 < a.T ? t + 2 : a.T - 1, g);
-    __builtin_amdgcn_sched_barrier(0);
-    const __hip_bfloat16* hrow = hbuf + (cur * kSeqs + seq) * kHPitch + 8 * q;
-    f32x4 acc[2][3][2];
-#pragma unroll
-    for (int l = 0; l < 2; ++l)
-#pragma unroll
-      for (int gate = 0; gate < 3; ++gate)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[l][gate][s][i] = 0.0f;
-#pragma unroll
-    for (int l = 0; l < 2; ++l) {
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        const bf16x8 hfrag = *reinterpret_cast<const bf16x8*>(hrow + 32 * kk);
-#pragma unroll
-        for (int gate = 0; gate < 3; ++gate)
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            // hipcc keeps MFMA operands in the VGPR half and uses the accumulator half as spill space (420 copies and
-            // 1.1 KB of scratch per lane when left to itself): the "a" constraint pins 64 of the 96 fragments there
-            if (l == 0 || gate == 0)
-              asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[l][gate][s]) : "a"(w[l][gate][s][kk]), "v"(hfrag));
-            else
-              asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[l][gate][s]) : "v"(w[l][gate][s][kk]), "v"(hfrag));
-          }
-      }
-      // the accumulators are read by VALU instructions next; for an MFMA inside an asm statement the compiler pads
-      // nothing (cdna_hip_programming.md 5.7 item 2): 8-pass MFMA -> VALU read needs 11 wait states
-      asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[l][0][0]), "+v"(acc[l][0][1]), "+v"(acc[l][1][0]), "+v"(acc[l][1][1]),
-                   "+v"(acc[l][2][0]), "+v"(acc[l][2][1]));
-    }
-#pragma unroll
-    for (int l = 0; l < 2; ++l) {
-      float ghr[kU], ghz[kU], gg[kU], rr[kU], zz[kU], nn[kU], hh[kU];
-      own_values(acc[l][0], ghr);
-      own_values(acc[l][1], ghz);
-      own_values(acc[l][2], gg);
-#pragma unroll
-      for (int i = 0; i < kU; ++i) {
-        gg[i] += bias_n[l][i];
-        rr[i] = sigmoid_f(gir[l][i] + ghr[i]);
-        zz[i] = sigmoid_f(giz[l][i] + ghz[i]);
-        nn[i] = tanh_f(fmaf(rr[i], gg[i], gin[l][i]));
-        hh[i] = fmaf(zz[i], h_prev[l][i] - nn[i], nn[i]);
-        h_prev[l][i] = hh[i];
-      }
-      *reinterpret_cast<Group<AsBF16>*>(hbuf + (nxt * kSeqs + seq) * kHPitch + unit0[l]) = enc1<AsBF16>(hh);
-      if (!kLdsY) *reinterpret_cast<Group<D>*>(y + (b * a.T + tt) * (2 * kH) + dir * kH + unit0[l]) = enc1<D>(hh);
-      if (kSave) {
-        PairOf<S>* const save_base = saved + tile_group(tile, a.T, tt, dir, 2 * pwave + l, 2, 0, lane);
-        save_base[0] = enc2<S>(rr, zz);
-        save_base[64] = enc2<S>(nn, gg);
-      }
-    }
-    __syncthreads();
-    if (kLdsY) {
-      // the 4 wavefronts write the kSeqs rows of the fresh h tile (512 B each) as contiguous runs
-      constexpr int kPer = kSeqs * kH / kGru4Threads;           // bf16 elements per lane: 4 (kSeqs = 4) or 8
-      const int row = tid * kPer / kH, col = tid * kPer % kH;
-      typedef Raw<2 * kPer> Piece;
-      const Piece v = *reinterpret_cast<const Piece*>(hbuf + (nxt * kSeqs + row) * kHPitch + col);
-      *reinterpret_cast<Piece*>(y + ((tile * kSeqs + row) * a.T + tt) * (2 * kH) + dir * kH + col) = v;
-    }
-  };
-
-  Group<D> g_a[2][3], g_b[2][3];
-  load_gi(0, g_a);
-  load_gi(a.T > 1 ? 1 : 0, g_b);
-  step(0, g_a);
-  long t = 1;
-#pragma unroll 1
-  for (; t + 1 < a.T; t += 2) {
-    step(t, g_b);
-    step(t + 1, g_a);
-  }
-  if (t < a.T) step(t, g_b);
-}
-
-template <typename T>
-__global__ __launch_bounds__(kGru4Threads, 1) void gru_forward4_kernel(GruFwdArgs a) {
-  static_assert(sizeof(T) == 2, "bf16 build only");
-  __shared__ __attribute__((aligned(16))) __hip_bfloat16 hbuf[2 * kSeqs * kHPitch];
-  const int tid = threadIdx.x;
-  const int pwave = tid >> 6, lane = tid & 63;
-  const int q = lane >> 4, c = lane & 15;
-  const __hip_bfloat16* wsrc = a.w_hh + static_cast<long>(blockIdx.y) * kG * kH;
-  bf16x8 w[2][3][2][8];
-#pragma unroll
-  for (int l = 0; l < 2; ++l)
-#pragma unroll
-    for (int gate = 0; gate < 3; ++gate)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int unit = 32 * (2 * pwave + l) + 16 * s + c;
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk)
-          w[l][gate][s][kk] = *reinterpret_cast<const bf16x8*>(wsrc + static_cast<long>(gate * kH + unit) * kH + 32 * kk + 8 * q);
-      }
-  for (int i = tid; i < 2 * kSeqs * kHPitch; i += kGru4Threads) hbuf[i] = __float2bfloat16(0.0f);
-  __syncthreads();
-  if (a.saved) gru_forward4_steps<T, true>(a, hbuf, w);
-  else gru_forward4_steps<T, false>(a, hbuf, w);
+  if (a.saved) gru_forward_steps<T, true>(a, wn_lds, hbuf, wr, wz);
+  else gru_forward_steps<T, false>(a, wn_lds, hbuf, wr, wz);
 }
 
 struct GruBwdArgs {
@@ -771,9 +551,6 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_backward_kernel(GruBwdArgs
       wn_lds[((wave * 2 + s) * 8 + kk) * 64 + lane] =
           *reinterpret_cast<const bf16x8*>(wt + static_cast<long>(unit) * kG + 2 * kH + 32 * kk + 8 * q);
   }
-#ifdef SELD_GRU_SKEW
-  if (wave < 4) __builtin_amdgcn_s_setprio(SELD_GRU_SKEW);
-#endif
   __syncthreads();
   gru_backward_steps<T>(a, wn_lds, dgh, wrz);
 }
@@ -929,32 +706,17 @@ int seld_gru_forward(const void* gi, int is_bf16, const void* w_hh_bf16, const f
   const size_t lds = kWnBytes + 2 * kSeqs * kHPitch * sizeof(__hip_bfloat16);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (need_lds(st, kAttrGruForward)) {     // once per device (seld_common.h)
-    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_forward_kernel<__hip_bfloat16, 0>),
+    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_forward_kernel<__hip_bfloat16>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_forward_kernel<__hip_bfloat16, 1>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_forward_kernel<float, 0>),
+    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_forward_kernel<float>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     lds_attr_set(st, kAttrGruForward);
   }
-  // SELD_GRU_FORWARD=4 selects the 4-wavefront all-register kernel (developer A/B).  Measured, B = 32, T = 250, same
-  // box, alternating processes: 8 wavefronts 1.15 us/step (289 us), 4 wavefronts 1.57 us/step (392 us): with ONE
-  // wavefront per SIMD nothing runs in the shadow of its own MFMAs or of its gate math -- the two co-resident
-  // wavefronts of the 8-wavefront kernel overlap each other's phases, which is worth more than the LDS weight reads cost.
-  static const int variant = [] {
-    const char* v = getenv("SELD_GRU_FORWARD");
-    return v && v[0] == '4' ? 4 : v && v[0] == 'g' ? 1 : 8;      // 'g': gate-major MFMA order (bf16)
-  }();
-  if (variant == 4 && is_bf16) {          // (the fp32 instantiation of the 4-wavefront kernel spills: 8 wavefronts there)
-    hipLaunchKernelGGL(gru_forward4_kernel<__hip_bfloat16>, grid, dim3(kGru4Threads), 0, stream, a);
-  } else {
-    if (is_bf16 && variant == 1)
-      hipLaunchKernelGGL((gru_forward_kernel<__hip_bfloat16, 1>), grid, dim3(kGruThreads), lds, stream, a);
-    else if (is_bf16)
-      hipLaunchKernelGGL((gru_forward_kernel<__hip_bfloat16, 0>), grid, dim3(kGruThreads), lds, stream, a);
-    else
-      hipLaunchKernelGGL((gru_forward_kernel<float, 0>), grid, dim3(kGruThreads), lds, stream, a);
-  }
+  // (Round 2 measured two variants against this kernel and dropped them: all of W_hh in registers with four wavefronts,
+  // 36 % slower -- one wavefront per SIMD has nothing to run in the shadow of its own MFMAs; gate-major MFMA order, no
+  // change.  DESIGN.md 5.4.)
+  if (is_bf16) hipLaunchKernelGGL(gru_forward_kernel<__hip_bfloat16>, grid, dim3(kGruThreads), lds, stream, a);
+  else hipLaunchKernelGGL(gru_forward_kernel<float>, grid, dim3(kGruThreads), lds, stream, a);
   SELD_HIP_TRY(hipGetLastError());
   return kOk;
 }

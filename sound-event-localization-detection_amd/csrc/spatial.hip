@@ -341,7 +341,6 @@ struct GccMfmaArgs {
   long N, C, F;
   long sN, sC, sM, sT;
   const void* table;     // kGmTableBytes of fp16 B fragments (build_gcc_table)
-  long long* stamps;     // developer instrumentation (SELD_GCC_STAMPS): per-wavefront cycle sums of the loop phases, or null
 };
 
 // Value of element j (0..7) of lane `lane` of fragment (part, tile, kstep) of the table: T[n][k] with k = 32 kstep +
@@ -556,11 +555,8 @@ __global__ __launch_bounds__(kGmThreads, 1) void gcc_mfma_kernel(GccMfmaArgs a) 
   if (tid < 2) flags[tid] = 0;
   __syncthreads();                                                 // the table and the zeroed buffers are in place
   int parity = 0;
-  long long ph[5] = {0, 0, 0, 0, 0};                              // barrier A, staging, request + barrier B, products, (count)
   auto iteration = [&](float2 (&pre)[8][kGmBinsPerLane]) {
-    long long t0 = a.stamps ? static_cast<long long>(__builtin_readcyclecounter()) : 0;
     lds_barrier();                                                 // the previous frames' readers are done
-    if (a.stamps) { const long long t1 = static_cast<long long>(__builtin_readcyclecounter()); ph[0] += t1 - t0; t0 = t1; }
     if (tid == 0) flags[parity ^ 1] = 0;                           // (read last in the previous iteration)
     int zero = 0;
 #pragma unroll
@@ -591,27 +587,20 @@ __global__ __launch_bounds__(kGmThreads, 1) void gcc_mfma_kernel(GccMfmaArgs a) 
     }
     if (__builtin_amdgcn_ballot_w64(zero != 0) != 0 && lane == 0) flags[parity] = 1;
     __builtin_amdgcn_sched_barrier(0);
-    if (a.stamps) { const long long t1 = static_cast<long long>(__builtin_readcyclecounter()); ph[1] += t1 - t0; t0 = t1; }
     request(frame_base(clamp_frame(f + stride)), pre);             // the slot's next frame: in flight across the products
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();
     const int has_zero = flags[parity];
-    if (a.stamps) { const long long t1 = static_cast<long long>(__builtin_readcyclecounter()); ph[2] += t1 - t0; t0 = t1; }
     if (f < total && mt < n_tiles) {
       const long n = f / a.F;
       const long t = f - n * a.F;
       if (has_zero) gcc_mfma_frame<true>(a, u, table, lane, mt, n_pairs, n, t);
       else gcc_mfma_frame<false>(a, u, table, lane, mt, n_pairs, n, t);
     }
-    if (a.stamps) { const long long t1 = static_cast<long long>(__builtin_readcyclecounter()); ph[3] += t1 - t0; ph[4] += 1; }
     f += stride;
     parity ^= 1;
   };
   for (long f0 = 2L * blockIdx.x; f0 < total; f0 += stride) iteration(pre_a);   // uniform trip count for the workgroup
-  if (a.stamps && lane == 0 && blockIdx.x < 64) {
-#pragma unroll
-    for (int k = 0; k < 5; ++k) a.stamps[(blockIdx.x * kGmWaves + wave) * 5 + k] = ph[k];
-  }
 }
 
 
@@ -692,9 +681,7 @@ int seld_gcc_phat(const float* spec_complex, int64_t N, int64_t C, int64_t F, fl
   // the matrix-core kernel stores four consecutive lags as one vector: unit lag stride, 16-byte aligned rows
   const bool vector_rows = sM == 1 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && sN % 4 == 0 && sC % 4 == 0 && sT % 4 == 0;
   if (!use_fft && vector_rows) {
-    GccMfmaArgs a{spec_complex, out, N, C, F, sN, sC, sM, sT, st->gcc_table, nullptr};
-    static const bool want_stamps = getenv("SELD_GCC_STAMPS") != nullptr;      // developer instrumentation
-    if (want_stamps) SELD_HIP_TRY(hipMalloc(&a.stamps, 64 * kGmWaves * 5 * sizeof(long long)));
+    GccMfmaArgs a{spec_complex, out, N, C, F, sN, sC, sM, sT, st->gcc_table};
     long blocks = (N * F + 1) / 2;
     if (blocks > st->num_cus) blocks = st->num_cus;         // persistent: the 96 KB table is staged once per workgroup
     if (need_lds(st, kAttrGccMfma)) {
@@ -705,18 +692,6 @@ int seld_gcc_phat(const float* spec_complex, int64_t N, int64_t C, int64_t F, fl
     hipLaunchKernelGGL(gcc_mfma_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kGmThreads), kGmLdsBytes,
                        static_cast<hipStream_t>(stream_), a);
     SELD_HIP_TRY(hipGetLastError());
-    if (want_stamps) {
-      std::vector<long long> h(64 * kGmWaves * 5);
-      SELD_HIP_TRY(hipMemcpy(h.data(), a.stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-      double sum[5] = {0, 0, 0, 0, 0};
-      const long nb = blocks < 64 ? blocks : 64;
-      for (long i = 0; i < nb * kGmWaves; ++i)
-        for (int k = 0; k < 5; ++k) sum[k] += static_cast<double>(h[i * 5 + k]);
-      fprintf(stderr, "gcc_mfma stamps (cycles per iteration and wavefront): barrier A %.0f, staging %.0f, request + barrier B %.0f, "
-              "products + stores %.0f (%.0f iterations)\n", sum[0] / sum[4], sum[1] / sum[4], sum[2] / sum[4], sum[3] / sum[4],
-              sum[4] / (nb * kGmWaves));
-      (void)hipFree(a.stamps);
-    }
     return kOk;
   }
   GccArgs a{spec_complex, out, N, C, F, sN, sC, sM, sT, st->tables()};

@@ -207,6 +207,26 @@ class _WindowTable:
                 "end_frame": min(start + ds.window_length_frames, ds.total_frames)}
 
 
+def save_compact_features(path, spec, mask):
+    """Write one recording's compact features to ``path`` so that a concurrent reader sees nothing or the whole file.
+    Data-parallel runs construct the dataset on every rank at once: each writer gets its OWN temporary file (same
+    directory, so the rename stays on one file system) and renames it into place; the loser of the race replaces the
+    winner's file with identical bytes."""
+    import os
+    import tempfile
+    path = Path(path)
+    path.parent.mkdir(parents=True, exist_ok=True)
+    fd, tmp = tempfile.mkstemp(prefix=path.stem + ".", suffix=".tmp.npz", dir=path.parent)
+    try:
+        with os.fdopen(fd, "wb") as handle:
+            np.savez(handle, spec=spec, mask=mask)
+        os.replace(tmp, path)
+    except BaseException:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+        raise
+
+
 class SELDDataset(Dataset):
     """All recordings -> one concatenated timeline -> 5 s windows with 1 s hop (dataset.py:167-330).
 
@@ -240,7 +260,8 @@ class SELDDataset(Dataset):
     def _cache_path(self, audio_path, metadata_path):
         """Where this recording's compact features live under Config.FEATURE_CACHE_DIR, or None (cache off; Gaussian
         label augmentation draws fresh noise per construction, smrl_seld_gaussian.py:397-534, so it is never cached).
-        The name carries everything the arrays depend on: both files' size and mtime, the feature set, the grid."""
+        The name carries everything the arrays depend on: both files' size and mtime, the feature set and the signal
+        parameters behind it (FFT size, hop, mel bands), the grid, the class count."""
         root = getattr(config, "FEATURE_CACHE_DIR", None)
         if not root or self.use_gaussian_augmentation:
             return None
@@ -248,7 +269,9 @@ class SELDDataset(Dataset):
         a, m = Path(audio_path), Path(metadata_path)
         sa, sm = a.stat(), m.stat()
         key = "|".join(str(v) for v in (a.resolve(), sa.st_size, sa.st_mtime_ns, m.resolve(), sm.st_size, sm.st_mtime_ns,
-                                        getattr(config, "FEATURE_SET", "logmel"), self.I, self.J, self.sample_rate, "v1"))
+                                        getattr(config, "FEATURE_SET", "logmel"), self.I, self.J, self.sample_rate,
+                                        config.SPECTROGRAM_N_FFT, config.SPECTROGRAM_HOP_LENGTH, config.N_MELS,
+                                        self.num_classes, getattr(config, "GRID_CELL_DEGREES", 10), "v2"))
         return Path(root) / f"{a.stem}.{hashlib.sha1(key.encode()).hexdigest()[:16]}.npz"
 
     def _file_features(self, audio_path, metadata_path):
@@ -261,11 +284,8 @@ class SELDDataset(Dataset):
             with np.load(cached) as z:
                 return torch.from_numpy(z["spec"]).to(self.device), torch.from_numpy(z["mask"]).to(self.device)
         spec, mask = self._file_features_uncached(audio_path, metadata_path)
-        if cached is not None:
-            cached.parent.mkdir(parents=True, exist_ok=True)
-            tmp = cached.with_suffix(".tmp.npz")
-            np.savez(tmp, spec=spec.cpu().numpy(), mask=mask.cpu().numpy())
-            tmp.replace(cached)                                # atomic: a concurrent rank sees nothing or the whole file
+        if cached is not None and not cached.exists():
+            save_compact_features(cached, spec.cpu().numpy(), mask.cpu().numpy())
         return spec, mask
 
     def _file_features_uncached(self, audio_path, metadata_path):

@@ -34,6 +34,8 @@ class _Conv3x3(torch.autograd.Function):
             y = F.conv2d(xc, wc, padding=1)
         ctx.save_for_backward(xc, wc)
         ctx.dtypes = (x.dtype, weight.dtype)
+        # the input is a backward-pass cut leaf (seld_cut.boundary): this convolution's backward ends a stage
+        ctx.after_cut = bool(x.is_leaf and x.requires_grad)
         return y
 
     @staticmethod
@@ -60,7 +62,7 @@ class _Conv3x3(torch.autograd.Function):
                 def job():
                     dw.copy_(torch.ops.aten.convolution_backward(dy, xc, wc, None, (1, 1), (1, 1), (1, 1), False, (0, 0),
                                                                  1, (False, True, False))[1])
-                seld_overlap.launch_now(dy.device, [dy, xc, wc, dw], job)
+                seld_overlap.launch_now(dy.device, [dy, xc, wc, dw], job, last_of_stage=ctx.after_cut)
                 return dx, dw
             dw = torch.ops.aten.convolution_backward(dy, xc, wc, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
                                                      (False, True, False))[1]
@@ -121,10 +123,16 @@ def run_cnn_blocks(blocks, x):
         dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() and x.is_floating_point() else x.dtype
         x = x.to(dtype=dtype, memory_format=torch.channels_last)
         import seld_convtail
+        import seld_cut
         with seld_convtail.batched_counters():          # one launch for the blocks' num_batches_tracked increments
-            for block in blocks:
+            for depth, block in enumerate(blocks):
                 x = block(x)
-        return x
+                # backward-pass cut points of the data-parallel captured step (identity otherwise): before the last
+                # block -- GRU layer 0's weight gradients, carried over from the recurrent stage, are computed beside
+                # that block's data gradient and travel under the rest -- and at the encoder's output
+                if depth == len(blocks) - 2:
+                    x = seld_cut.boundary(x)
+        return seld_cut.boundary(x)
     for block in blocks:
         x = block(x)
     return x

@@ -85,7 +85,14 @@ class ResNet50Encoder(nn.Module):
         else:
             x = self.relu(self.bn1(x))
         x = self.maxpool(x)
-        return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        x = self.layer3(self.layer2(self.layer1(x)))
+        if x.is_cuda:
+            # backward-pass cut points of the data-parallel captured step (identity otherwise, seld_cut.py): the
+            # Conformer + head gradients (72 MB bf16) travel under the whole encoder backward, layer4's (30 MB) under
+            # layer3..stem
+            import seld_cut
+            return seld_cut.boundary(self.layer4(seld_cut.boundary(x)))
+        return self.layer4(x)
 
 
 class SELD_ResNet50_Conformer(nn.Module):

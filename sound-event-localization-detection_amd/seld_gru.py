@@ -102,8 +102,9 @@ class _BiGRULayer(torch.autograd.Function):
                 # on the side stream, beside the recurrence of the layer below (seld_overlap.launch_pending there)
                 seld_overlap.submit(dy.device, [dgi, dghn, y, xc, dw_ih, dw_hh], weight_grads)
             elif seld_overlap.conv_wgrad_side and seld_overlap.enabled and dy.is_cuda:
-                # layer 0 under the captured step: beside the convolution backward (joined by the stepper)
-                seld_overlap.launch_now(dy.device, [dgi, dghn, y, xc, dw_ih, dw_hh], weight_grads)
+                # layer 0 under the captured step: beside the convolution backward (joined by the stepper; carried over
+                # to the next backward stage when the data-parallel step cuts the pass below this layer)
+                seld_overlap.launch_now(dy.device, [dgi, dghn, y, xc, dw_ih, dw_hh], weight_grads, last_of_stage=True)
             else:
                 weight_grads()
             db_ih, db_hh = seld_native.gru_bias_grads(dbias)                       # [6H], [6H] fp32, one launch

@@ -25,14 +25,40 @@ import torch
 import seld_native
 
 enabled = os.environ.get("SELD_OVERLAP", "1") != "0"      # Config.OVERLAP_WEIGHT_GRADS via trainer.prepare_model_for_device
+# Two side streams per device.  0: the ``submit`` jobs (head / GRU layer 1 weight gradients), which the ``_Deferred`` node
+# joins right after GRU layer 0's recurrence.  1: the ``launch_now`` jobs (GRU layer 0's and the convolutions' weight
+# gradients), joined by the stepper at the end of the backward pass.  With ONE stream (round 2) the _Deferred join also
+# waited for layer 0's weight gradients, enqueued on the same stream a moment earlier: the convolution backward started
+# ~140 us late (profiles/r02_iteration_timeline.txt, t = 1053 .. 1207 us).  SELD_SIDE_STREAMS=1 restores that for A/B runs.
+two_streams = os.environ.get("SELD_SIDE_STREAMS", "2") != "1"
 _streams = {}
+_dirty = set()      # (device index, which): work enqueued on that side stream since the main stream last waited for it
 
 
-def side_stream(device):
-    index = device.index if device.index is not None else torch.cuda.current_device()
-    if index not in _streams:
-        _streams[index] = torch.cuda.Stream(device=index)
-    return _streams[index]
+def _index(device):
+    if device.index is not None:
+        return device.index
+    return torch.cuda.current_device() if device.type == "cuda" else -1
+
+
+def side_stream(device, which=0):
+    key = (_index(device), which if two_streams else 0)
+    if key not in _streams:
+        _streams[key] = torch.cuda.Stream(device=key[0])
+    return _streams[key]
+
+
+def _mark(device, which):
+    _dirty.add((_index(device), which if two_streams else 0))
+
+
+def _wait(device, which):
+    """The main stream waits for side stream ``which`` if anything was enqueued there since the last wait (a wait on an
+    idle stream would record an event outside a graph capture in flight)."""
+    key = (_index(device), which if two_streams else 0)
+    if key in _dirty:
+        _dirty.discard(key)
+        torch.cuda.current_stream(device).wait_stream(side_stream(device, which))
 
 
 def active(x):
@@ -59,8 +85,9 @@ def launch_pending(device):
     jobs = list(_pending)
     del _pending[:]
     main = torch.cuda.current_stream(device)
-    side = side_stream(device)
+    side = side_stream(device, 0)
     side.wait_stream(main)
+    _mark(device, 0)
     with torch.cuda.stream(side):
         if head_start_ns:
             seld_native.stream_delay(device, head_start_ns)
@@ -80,24 +107,57 @@ def launch_pending(device):
 # under DistributedDataParallel the reducer's hooks read gradients when autograd delivers them, so the eager path keeps
 # everything on one stream.
 conv_wgrad_side = False
+# A backward pass cut into stages (seld_cut.py, seld_graph.py): every stage is its own HIP graph, so a job launched in
+# stage k has to be joined before stage k ends -- a weight gradient that becomes computable at the very end of a stage
+# (GRU layer 0's, the last convolution's of the stage) would then run alone instead of beside the next stage.  While
+# ``carry`` is set such jobs (``last_of_stage``) are kept and ``launch_carried`` starts them at the head of the NEXT stage; the gradient
+# tensors they fill are not final until that stage's join (``carried_storages``: the stepper keeps those parameters out
+# of the earlier stage's all-reduce bucket).
+carry = False
+_carried = []
 
 
-def launch_now(device, tensors, job):
-    """Run ``job()`` on the side stream behind what the main stream holds now; ``join`` must follow before the results
-    are read on the main stream."""
+def launch_now(device, tensors, job, last_of_stage=False):
+    """Run ``job()`` on side stream 1 behind what the main stream holds now; ``join`` must follow before the results
+    are read on the main stream.  ``last_of_stage``: the caller is the last node of a backward stage when a cut follows
+    it (GRU layer 0; the convolution that consumes a ``seld_cut.boundary`` leaf) -- carried over while ``carry`` is set."""
+    if carry and last_of_stage:
+        _carried.append((device, tensors, job))
+        return
     main = torch.cuda.current_stream(device)
-    side = side_stream(device)
+    side = side_stream(device, 1)
     side.wait_stream(main)
+    _mark(device, 1)
     with torch.cuda.stream(side):
         job()
     for t in tensors:
         t.record_stream(side)
 
 
+def launch_carried(device):
+    """Start the jobs the previous stage carried over (head of a stage, before its backward pass is enqueued)."""
+    global carry
+    jobs = list(_carried)
+    del _carried[:]
+    was, carry = carry, False
+    try:
+        for dev, tensors, job in jobs:
+            launch_now(dev, tensors, job)
+    finally:
+        carry = was
+    return len(jobs)
+
+
+def carried_storages():
+    """Storage addresses of the tensors queued jobs will still write (their gradients are not final yet)."""
+    return {t.untyped_storage().data_ptr() for _, tensors, _ in _carried for t in tensors}
+
+
 def join(device):
-    """The main stream waits for everything queued on the side stream (pending jobs are launched first)."""
+    """The main stream waits for everything queued on the side streams (pending jobs are launched first)."""
     launch_pending(device)
-    torch.cuda.current_stream(device).wait_stream(side_stream(device))
+    _wait(device, 0)
+    _wait(device, 1)
 
 
 class _Deferred(torch.autograd.Function):
@@ -110,13 +170,14 @@ class _Deferred(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, *grads):
         launch_pending(ctx.device)
-        torch.cuda.current_stream(ctx.device).wait_stream(side_stream(ctx.device))
+        _wait(ctx.device, 0)
         return grads
 
 
 def defer(*params):
     """Aliases of ``params`` whose gradients may be produced by ``submit``-ted jobs."""
     del _pending[:]           # jobs of a backward pass that was abandoned by an exception: their graph is gone
+    del _carried[:]
     return _Deferred.apply(*params)
 
 

@@ -32,7 +32,7 @@ from pathlib import Path
 import numpy as np
 import torch
 import torch.distributed as dist
-from torch.utils.data import DataLoader, RandomSampler  # noqa: F401
+from torch.utils.data import DataLoader, RandomSampler, SequentialSampler  # noqa: F401
 from tqdm import tqdm
 
 from config import Config
@@ -229,9 +229,20 @@ class LoaderFeed:
     def __init__(self, loader, device, rank=0, world=1, seed=0):
         self.loader, self.device = loader, device
         self.rank, self.world, self.seed = rank, world, seed
-        self.shuffle = isinstance(getattr(loader, "sampler", None), RandomSampler)
+        sampler = getattr(loader, "sampler", None)
+        self.shuffle = isinstance(sampler, RandomSampler)
         if world > 1 and getattr(loader, "batch_size", None) is None:
             raise ValueError("data-parallel training needs a DataLoader with a batch_size (got a batch_sampler-only loader)")
+        if world > 1 and not isinstance(sampler, (RandomSampler, SequentialSampler)):
+            # a Weighted / SubsetRandom / custom sampler cannot be sharded by re-deriving its order: refuse instead of
+            # silently training on a different (sequential) order
+            raise ValueError(f"data-parallel training shards the epoch's index order itself and supports the stock "
+                             f"Random / Sequential samplers only (got {type(sampler).__name__})")
+        if world > 1:
+            n = len(loader.dataset)
+            if n % world:
+                logger.info(f"  data parallel: {world - n % world} window(s) of every epoch are seen twice (the index "
+                            f"order is padded by wrapping to a multiple of {world} ranks, DistributedSampler semantics)")
 
     def _batches_of_rank(self, epoch):
         order = shard_indices(epoch_order(len(self.loader.dataset), self.shuffle, self.seed, epoch), self.rank, self.world)
@@ -243,8 +254,15 @@ class LoaderFeed:
     def batches(self, epoch):
         loader = self.loader
         if self.world > 1:
+            # the caller's loader with this rank's batches: workers, collate function, pinning, worker initialisation,
+            # generator and prefetch depth are carried over
+            extra = {}
+            if loader.num_workers > 0:
+                extra = dict(prefetch_factor=loader.prefetch_factor, worker_init_fn=loader.worker_init_fn,
+                             multiprocessing_context=loader.multiprocessing_context)
             loader = DataLoader(loader.dataset, batch_sampler=self._batches_of_rank(epoch), num_workers=loader.num_workers,
-                                collate_fn=loader.collate_fn, pin_memory=loader.pin_memory)
+                                collate_fn=loader.collate_fn, pin_memory=loader.pin_memory, generator=loader.generator,
+                                timeout=loader.timeout, **extra)
         for spectrograms, labels in loader:
             yield (spectrograms.to(self.device, non_blocking=True), labels.to(self.device, non_blocking=True))
 
@@ -387,7 +405,11 @@ class MasterWeightAdam(torch.optim.Adam):
         import seld_native
         grads = [p.grad for p in self._low]
         master_grads = [m.grad for m in self._masters]
-        if all(g is not None for g in grads) and seld_native.multi_cast(grads, master_grads, self._grad_cast_cache):
+        if getattr(self, "external_master_grads", False):
+            # the data-parallel exchange reduced in fp32: the masters' gradients ARE the all-reduced flat buffer's views
+            # (seld_graph.FlatGradients, wire dtype "fp32"), nothing to cast
+            self.fused_casts += 1
+        elif all(g is not None for g in grads) and seld_native.multi_cast(grads, master_grads, self._grad_cast_cache):
             self.fused_casts += 1
         else:
             self.fallback_casts += 1
@@ -436,14 +458,28 @@ def make_stepper(model, criterion, optimizer, device, world=1):
     if graph_step_enabled(device, world) and not isinstance(model, torch.nn.parallel.DistributedDataParallel):
         import seld_graph
         return seld_graph.GraphedTrainStep(model, criterion, optimizer, device, world,
-                                           autocast=lambda: autocast_context(device))
+                                           autocast=lambda: autocast_context(device),
+                                           overlap_allreduce=bool(getattr(config, "OVERLAP_ALLREDUCE", True)),
+                                           reduce_dtype=getattr(config, "GRAD_REDUCE_DTYPE", "param"))
     return lambda spectrograms, labels: train_step(model, criterion, optimizer, spectrograms, labels, device)
 
 
 def checkpoint_payload(epoch, model, optimizer, train_loss, test_loss):
-    """The dict format of trainer.py:278-285 (the Config INSTANCE is pickled, as upstream)."""
+    """The dict format of trainer.py:278-285 (the Config INSTANCE is pickled, as upstream).  A capturable Adam keeps its
+    learning rate (and step counts) in device tensors; the file holds what the reference's plain Adam would have written --
+    a float learning rate, host-side step counts, no ``capturable`` flag -- so that upstream code can format, compare or
+    resume from it on any box."""
+    opt_state = optimizer.state_dict()
+    for group in opt_state.get("param_groups", []):
+        if isinstance(group.get("lr"), torch.Tensor):
+            group["lr"] = float(group["lr"])
+        if group.get("capturable"):
+            group["capturable"] = False
+    for entry in opt_state.get("state", {}).values():
+        if isinstance(entry.get("step"), torch.Tensor):
+            entry["step"] = entry["step"].detach().float().cpu()
     return {"epoch": epoch, "model_state_dict": model_state_dict(model),
-            "optimizer_state_dict": optimizer.state_dict(), "train_loss": train_loss, "test_loss": test_loss,
+            "optimizer_state_dict": opt_state, "train_loss": train_loss, "test_loss": test_loss,
             "config": config}
 
 

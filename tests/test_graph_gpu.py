@@ -30,7 +30,7 @@ def _batches(device, n, batch, channels=4, seed=3):
     return out
 
 
-def _train(kind, device, graphs, batches, lr_change_at=None, wgrad_side=True):
+def _train(kind, device, graphs, batches, lr_change_at=None, wgrad_side=True, split=False):
     """``graphs`` False: the same stepper object run eagerly (same optimiser: capturable fused Adam, device-side
     learning rate and step count -- the non-capturable Adam rounds the step size differently in the last bit)."""
     import seld_graph
@@ -45,7 +45,7 @@ def _train(kind, device, graphs, batches, lr_change_at=None, wgrad_side=True):
         crit = trainer.SMRSELDLoss("mse", 1.0, grid_size=(18, 36))
         opt = trainer.make_optimizer(model, 1e-3, device, capturable=True)
         step = seld_graph.GraphedTrainStep(model, crit, opt, device, autocast=lambda: trainer.autocast_context(device),
-                                           use_graphs=graphs)
+                                           use_graphs=graphs, split=split)
         step.wgrad_side = wgrad_side
         losses = []
         for i, (x, m) in enumerate(batches):
@@ -109,3 +109,66 @@ def test_other_models_capture_and_track_the_eager_loop(gpu_device, kind):
     assert stats["capture_error"] is None and stats["graphs"] >= 1 and stats["replays"] >= 4
     assert torch.isfinite(graph).all()
     assert (eager - graph).abs().max().item() <= 2e-2 * eager.abs().max().item()
+
+
+def test_staged_capture_is_bit_identical_to_the_single_graph(gpu_device):
+    """``split=True`` captures what the data-parallel path replays -- one graph per backward stage (cut at the model's
+    seld_cut.boundary points, GRU layer 0's and the last block's weight gradients carried over to the next stage), flat
+    gradient buckets, a separate update graph -- on one rank without collectives.  Same kernels on the same numbers:
+    losses and weights must equal the single-graph iteration's bit for bit."""
+    batches = _batches(gpu_device, 24, 8)
+    was = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        one, sd_one, st_one = _train("crnn", gpu_device, True, batches, lr_change_at=12)
+        cut, sd_cut, st_cut = _train("crnn", gpu_device, True, batches, lr_change_at=12, split=True)
+        again, _, _ = _train("crnn", gpu_device, True, batches, lr_change_at=12)
+    finally:
+        torch.backends.cudnn.deterministic = was
+    assert st_cut["capture_error"] is None and st_cut["graphs"] == 2 and st_cut["backward_stages"] == 3
+    assert "backward_stages" not in st_one
+    assert [b["stage"] for b in st_cut["gradient_buckets"]] == [0, 1, 2]
+    assert all(b["bytes"] > 0 for b in st_cut["gradient_buckets"])
+    assert torch.isfinite(cut).all() and cut[-1] < cut[0]
+    if torch.equal(one, again):
+        assert torch.equal(one, cut), (one - cut).abs().max().item()
+        for k in sd_one:
+            assert torch.equal(sd_one[k], sd_cut[k]), k
+    else:                                                                       # not reproducible run to run: within its spread
+        spread = (one - again).abs().max().item()
+        assert (one - cut).abs().max().item() <= 4 * spread + 1e-7
+
+
+@pytest.mark.parametrize("kind", ["conformer", "resnet_conformer"])
+def test_other_models_staged_capture(gpu_device, kind):
+    """The cut points of the Conformer (shared encoder) and of the ResNet50-Conformer (after the encoder, before layer4)."""
+    batches = _batches(gpu_device, 8, 2)
+    one, _, _ = _train(kind, gpu_device, True, batches)
+    cut, _, stats = _train(kind, gpu_device, True, batches, split=True)
+    assert stats["capture_error"] is None and stats["backward_stages"] == 3
+    sizes = [b["bytes"] for b in stats["gradient_buckets"]]
+    assert sizes[0] > 0 and sizes[2] > 0
+    assert torch.isfinite(cut).all()
+    assert (one - cut).abs().max().item() <= 2e-2 * one.abs().max().item()
+
+
+def test_conformer_captured_iterations_at_batch_32(gpu_device):
+    """BASELINE configs[2] at size: the Conformer (model_conformer.py) at batch 32 x 250 frames through the captured
+    step -- three eager iterations, capture, replays -- on one repeated batch: finite losses that decrease, logits of
+    the contract's shape from the trained weights."""
+    import trainer
+    x, m = _batches(gpu_device, 1, 32)[0]
+    losses, sd, stats = _train("conformer", gpu_device, True, [(x, m)] * 9)
+    assert stats["capture_error"] is None and stats["graphs"] == 1 and stats["replays"] == 6
+    assert torch.isfinite(losses).all() and losses[-1] < losses[0] and losses[-1] < losses[3]
+    cfg = trainer.config
+    saved = cfg.MODEL_TYPE
+    cfg.MODEL_TYPE = "conformer"
+    try:
+        model = trainer.prepare_model_for_device(trainer.build_model((18, 36)), gpu_device)
+        model.load_state_dict(sd)
+        with torch.no_grad(), trainer.autocast_context(gpu_device):
+            logits = model.eval()(x)
+    finally:
+        cfg.MODEL_TYPE = saved
+    assert tuple(logits.shape) == (32, 250, 648, 14) and torch.isfinite(logits.float()).all()

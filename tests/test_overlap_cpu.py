@@ -23,11 +23,15 @@ def streams(monkeypatch):
     main, side = _FakeStream("main", log), _FakeStream("side", log)
     monkeypatch.setattr(torch.cuda, "current_stream", lambda device=None: main)
     monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
-    monkeypatch.setattr(seld_overlap, "side_stream", lambda device: side)
+    monkeypatch.setattr(seld_overlap, "side_stream", lambda device, which=0: side)
     monkeypatch.setattr(seld_overlap, "head_start_ns", 0)           # the delay kernel needs the HIP library
     del seld_overlap._pending[:]
+    del seld_overlap._carried[:]
+    seld_overlap._dirty.clear()
     yield log
     del seld_overlap._pending[:]
+    del seld_overlap._carried[:]
+    seld_overlap._dirty.clear()
 
 
 class _Consumer(torch.autograd.Function):
@@ -110,3 +114,24 @@ def test_linear_alias_lives_for_one_forward_pass_only(streams):
     y = lin(torch.randn(2, 3))                             # CPU tensor: stock nn.Linear, but the alias is consumed
     assert "_deferred" not in lin.__dict__ and tuple(y.shape) == (2, 5)
     assert set(lin.state_dict()) == {"weight", "bias"}     # the alias never shows up as a parameter or buffer
+
+
+def test_carried_jobs_wait_for_the_next_stage(streams):
+    """A backward pass cut into stages (seld_cut.py): while ``carry`` is set a ``launch_now`` job is kept, its tensors
+    are reported as unfinished, and ``launch_carried`` starts it on side stream 1 at the head of the next stage."""
+    log = streams
+    out = torch.zeros(3)
+    seld_overlap.carry = True
+    try:
+        seld_overlap.launch_now(torch.device("cpu"), [out], lambda: (log.append("carried job runs"), out.fill_(1.0)),
+                                last_of_stage=True)
+    finally:
+        seld_overlap.carry = False
+    assert log == [] and out.untyped_storage().data_ptr() in seld_overlap.carried_storages()
+    seld_overlap.join(torch.device("cpu"))                  # the stage's own join has nothing to wait for
+    assert log == []
+    out.record_stream = lambda stream: None                 # CPU tensor standing in for a device allocation
+    assert seld_overlap.launch_carried(torch.device("cpu")) == 1
+    assert log == ["side waits for main", "carried job runs"] and not seld_overlap.carried_storages()
+    seld_overlap.join(torch.device("cpu"))
+    assert log[-1] == "main waits for side" and out.sum() == 3

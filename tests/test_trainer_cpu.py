@@ -123,3 +123,72 @@ def test_data_parallel_two_ranks_gloo(tmp_path):
     assert cfg1["batches_per_rank"] == 2
     assert not set(seen0) & set(seen1) and sorted(seen0 + seen1) == list(range(8))
     assert (Path(tmp_path) / "checkpoints" / "best_model.pth").exists()
+
+
+def _cache_writer(path, seed, barrier, queue):
+    for p in (str(ROOT), str(PKG)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import numpy as np
+    import dataset
+    rng = np.random.default_rng(0)                       # every rank computes the same features
+    spec = rng.standard_normal((400, 4, 64)).astype(np.float32)
+    mask = rng.integers(0, 1 << 14, (400, 648)).astype(np.uint16)
+    barrier.wait()
+    try:
+        for _ in range(20):                              # hammer the same final name from every process
+            dataset.save_compact_features(path, spec, mask)
+            with np.load(path) as z:
+                assert np.array_equal(z["spec"], spec) and np.array_equal(z["mask"], mask)
+        queue.put((seed, "ok"))
+    except Exception as exc:      # noqa: BLE001
+        queue.put((seed, f"{type(exc).__name__}: {exc}"))
+
+
+def test_feature_cache_writers_do_not_collide(tmp_path):
+    """Config.FEATURE_CACHE_DIR under data parallelism: every rank builds the dataset and writes the SAME cache entry at
+    the same time (round 2 shared one temporary name: the second rename raised FileNotFoundError).  Four processes write
+    and re-read one entry 20 times each; nobody fails, no temporary file is left behind."""
+    ctx = mp.get_context("spawn")
+    queue, barrier = ctx.Queue(), ctx.Barrier(4)
+    target = tmp_path / "cache" / "clip.0123456789abcdef.npz"
+    procs = [ctx.Process(target=_cache_writer, args=(str(target), i, barrier, queue)) for i in range(4)]
+    for p in procs:
+        p.start()
+    results = sorted(queue.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in results] == ["ok"] * 4, results
+    assert sorted(f.name for f in target.parent.iterdir()) == [target.name]
+
+
+def test_checkpoint_holds_plain_adam_state(tmp_path):
+    """A capturable Adam keeps lr / step on the device; the checkpoint must hold what the reference's plain Adam writes
+    (trainer.py:278-285): a float learning rate, host step counts."""
+    import trainer
+    model = torch.nn.Linear(4, 3)
+    opt = torch.optim.Adam(model.parameters(), lr=torch.tensor(1e-3), capturable=False)
+    model(torch.randn(2, 4)).sum().backward()
+    opt.step()
+    payload = trainer.checkpoint_payload(3, model, opt, 0.5, 0.6)
+    group = payload["optimizer_state_dict"]["param_groups"][0]
+    assert isinstance(group["lr"], float) and abs(group["lr"] - 1e-3) < 1e-9
+    for entry in payload["optimizer_state_dict"]["state"].values():
+        assert not entry["step"].is_cuda
+    assert isinstance(opt.param_groups[0]["lr"], torch.Tensor)          # the live optimiser keeps its tensor
+    torch.save(payload, tmp_path / "c.pth")
+    again = torch.load(tmp_path / "c.pth", weights_only=False)
+    fresh = torch.optim.Adam(torch.nn.Linear(4, 3).parameters(), lr=1.0)
+    fresh.load_state_dict(again["optimizer_state_dict"])               # a plain Adam resumes from it
+    assert fresh.param_groups[0]["lr"] == group["lr"]
+
+
+def test_loader_feed_refuses_samplers_it_cannot_shard():
+    import trainer
+    from torch.utils.data import WeightedRandomSampler
+    ds = TinySeld(8, 1)
+    loader = DataLoader(ds, batch_size=2, sampler=WeightedRandomSampler([1.0] * 8, 8))
+    with pytest.raises(ValueError, match="Random / Sequential"):
+        trainer.LoaderFeed(loader, torch.device("cpu"), rank=0, world=2)
+    trainer.LoaderFeed(loader, torch.device("cpu"), rank=0, world=1)    # single process: the loader is used as it is

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 RAW=/tmp/prof_raw_$TAG
 rm -rf $RAW && mkdir -p $OUT $RAW
-rocprofv3 --kernel-trace --stats --output-format csv -d $RAW -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-rooflines "$@" > $OUT/bench_stdout.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $RAW -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-rooflines --no-other-workloads "$@" > $OUT/bench_stdout.log 2>&1
 find $RAW -name "*kernel_stats.csv" -exec cp {} $OUT/ \;
 # statistics of the timed region only (the whole-process summary above includes MIOpen's find-mode trials)
 find $RAW -name "*kernel_trace.csv" -exec python3 $GRAFT_REPO_ROOT/tools/trace_timed_region.py {} 2 $OUT/bench_timed_region_stats.csv \; > $OUT/timed_region.log 2>&1
