@@ -475,7 +475,10 @@ def checkpoint_payload(epoch, model, optimizer, train_loss, test_loss):
             group["lr"] = float(group["lr"])
         if group.get("capturable"):
             group["capturable"] = False
-    for entry in opt_state.get("state", {}).values():
+    # (state_dict() hands out the LIVE per-parameter state dicts: copy before touching them -- a host-side step count
+    # in the running capturable Adam would make its fused kernel dereference a host pointer)
+    opt_state["state"] = {k: dict(v) for k, v in opt_state.get("state", {}).items()}
+    for entry in opt_state["state"].values():
         if isinstance(entry.get("step"), torch.Tensor):
             entry["step"] = entry["step"].detach().float().cpu()
     return {"epoch": epoch, "model_state_dict": model_state_dict(model),

@@ -125,7 +125,7 @@ def test_staged_capture_is_bit_identical_to_the_single_graph(gpu_device):
         again, _, _ = _train("crnn", gpu_device, True, batches, lr_change_at=12)
     finally:
         torch.backends.cudnn.deterministic = was
-    assert st_cut["capture_error"] is None and st_cut["graphs"] == 2 and st_cut["backward_stages"] == 3
+    assert st_cut["capture_error"] is None and st_cut["graphs"] == 1 and st_cut["backward_stages"] == 3   # (the ragged shape is seen 3 times: eager)
     assert "backward_stages" not in st_one
     assert [b["stage"] for b in st_cut["gradient_buckets"]] == [0, 1, 2]
     assert all(b["bytes"] > 0 for b in st_cut["gradient_buckets"])

@@ -176,7 +176,9 @@ def test_checkpoint_holds_plain_adam_state(tmp_path):
     assert isinstance(group["lr"], float) and abs(group["lr"] - 1e-3) < 1e-9
     for entry in payload["optimizer_state_dict"]["state"].values():
         assert not entry["step"].is_cuda
-    assert isinstance(opt.param_groups[0]["lr"], torch.Tensor)          # the live optimiser keeps its tensor
+    assert isinstance(opt.param_groups[0]["lr"], torch.Tensor)          # the live optimiser keeps its tensor ...
+    live = next(iter(opt.state.values()))
+    assert payload["optimizer_state_dict"]["state"][0] is not live      # ... and its own state dicts (not the payload's)
     torch.save(payload, tmp_path / "c.pth")
     again = torch.load(tmp_path / "c.pth", weights_only=False)
     fresh = torch.optim.Adam(torch.nn.Linear(4, 3).parameters(), lr=1.0)
