@@ -62,8 +62,8 @@ class _Conv3x3(torch.autograd.Function):
                 def job():
                     dw.copy_(torch.ops.aten.convolution_backward(dy, xc, wc, None, (1, 1), (1, 1), (1, 1), False, (0, 0),
                                                                  1, (False, True, False))[1])
-                seld_overlap.launch_now(dy.device, [dy, xc, wc, dw], job, last_of_stage=ctx.after_cut)
-                return dx, dw
+                seld_overlap.launch_now(dy.device, [dy, xc, wc, dw], job, last_of_stage=ctx.after_cut, outputs=[dw])
+                return dx, dw.view_as(dw)          # a fresh alias: autograd takes it over instead of cloning (seld_overlap)
             dw = torch.ops.aten.convolution_backward(dy, xc, wc, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
                                                      (False, True, False))[1]
         return dx, dw if dw.dtype == w_dtype else dw.to(w_dtype)

@@ -278,6 +278,13 @@ class GraphedTrainStep:
             unfinished = seld_overlap.carried_storages()
             ready = [p for p in rest if p.grad is not None
                      and p.grad.untyped_storage().data_ptr() not in unfinished]
+            # every gradient a carried job will fill must still be aliased by a parameter's .grad: had autograd cloned
+            # it (it does when the tensor is referenced elsewhere) the clone would hold whatever was in memory
+            aliased = {p.grad.untyped_storage().data_ptr() for p in rest if p.grad is not None}
+            lost = seld_overlap.carried_outputs() - aliased
+            if lost:
+                raise RuntimeError(f"{len(lost)} weight gradient(s) handed over to the next backward stage are no longer "
+                                   f"aliased by a parameter's .grad (cloned by autograd before the side-stream job ran)")
         self.flat.add_bucket(ready, last)
 
     def _update(self):

@@ -104,13 +104,16 @@ class _BiGRULayer(torch.autograd.Function):
             elif seld_overlap.conv_wgrad_side and seld_overlap.enabled and dy.is_cuda:
                 # layer 0 under the captured step: beside the convolution backward (joined by the stepper; carried over
                 # to the next backward stage when the data-parallel step cuts the pass below this layer)
-                seld_overlap.launch_now(dy.device, [dgi, dghn, y, xc, dw_ih, dw_hh], weight_grads, last_of_stage=True)
+                seld_overlap.launch_now(dy.device, [dgi, dghn, y, xc, dw_ih, dw_hh], weight_grads, last_of_stage=True,
+                                        outputs=[dw_ih, dw_hh])
             else:
                 weight_grads()
             db_ih, db_hh = seld_native.gru_bias_grads(dbias)                       # [6H], [6H] fp32, one launch
             db_hh = db_hh.view(2, 3 * h)
+        # (fresh aliases of dw_ih / dw_hh: a queued job keeps its tensors referenced, and autograd clones a gradient that
+        # is referenced elsewhere -- before the job has filled it)
         return dx.to(dy.dtype) if dx.dtype != dy.dtype and not torch.is_autocast_enabled() else dx, \
-            dw_ih, db_ih.to(t_bih), dw_hh, db_hh.to(t_bhh), None, None
+            dw_ih.view_as(dw_ih), db_ih.to(t_bih), dw_hh.view_as(dw_hh), db_hh.to(t_bhh), None, None
 
 
 class _Joined(torch.autograd.Function):

@@ -117,12 +117,16 @@ carry = False
 _carried = []
 
 
-def launch_now(device, tensors, job, last_of_stage=False):
+def launch_now(device, tensors, job, last_of_stage=False, outputs=()):
     """Run ``job()`` on side stream 1 behind what the main stream holds now; ``join`` must follow before the results
     are read on the main stream.  ``last_of_stage``: the caller is the last node of a backward stage when a cut follows
-    it (GRU layer 0; the convolution that consumes a ``seld_cut.boundary`` leaf) -- carried over while ``carry`` is set."""
+    it (GRU layer 0; the convolution that consumes a ``seld_cut.boundary`` leaf) -- carried over while ``carry`` is set.
+    ``outputs``: the gradient tensors the job fills (a subset of ``tensors``).  The caller must hand autograd VIEWS of
+    them, not the tensors themselves: a carried job keeps its tensors referenced, and AccumulateGrad clones a gradient
+    that is referenced elsewhere -- on the main stream, before the job has run (``carried_outputs`` lets the stepper
+    check that every parameter gradient still aliases its job's output)."""
     if carry and last_of_stage:
-        _carried.append((device, tensors, job))
+        _carried.append((device, tensors, job, tuple(outputs)))
         return
     main = torch.cuda.current_stream(device)
     side = side_stream(device, 1)
@@ -141,7 +145,7 @@ def launch_carried(device):
     del _carried[:]
     was, carry = carry, False
     try:
-        for dev, tensors, job in jobs:
+        for dev, tensors, job, _ in jobs:
             launch_now(dev, tensors, job)
     finally:
         carry = was
@@ -150,7 +154,12 @@ def launch_carried(device):
 
 def carried_storages():
     """Storage addresses of the tensors queued jobs will still write (their gradients are not final yet)."""
-    return {t.untyped_storage().data_ptr() for _, tensors, _ in _carried for t in tensors}
+    return {t.untyped_storage().data_ptr() for _, tensors, _, _ in _carried for t in tensors}
+
+
+def carried_outputs():
+    """Storage addresses of the gradient tensors the queued jobs will fill."""
+    return {t.untyped_storage().data_ptr() for _, _, _, outputs in _carried for t in outputs}
 
 
 def join(device):

@@ -124,10 +124,11 @@ def test_carried_jobs_wait_for_the_next_stage(streams):
     seld_overlap.carry = True
     try:
         seld_overlap.launch_now(torch.device("cpu"), [out], lambda: (log.append("carried job runs"), out.fill_(1.0)),
-                                last_of_stage=True)
+                                last_of_stage=True, outputs=[out])
     finally:
         seld_overlap.carry = False
     assert log == [] and out.untyped_storage().data_ptr() in seld_overlap.carried_storages()
+    assert seld_overlap.carried_outputs() == {out.untyped_storage().data_ptr()}
     seld_overlap.join(torch.device("cpu"))                  # the stage's own join has nothing to wait for
     assert log == []
     out.record_stream = lambda stream: None                 # CPU tensor standing in for a device allocation
