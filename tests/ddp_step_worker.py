@@ -62,9 +62,11 @@ def main():
     if hasattr(step, "close"):
         step.close()
     sd = trainer.model_state_dict(model)
+    names = {n for n, _ in trainer.unwrap(model).named_parameters()}
     digest = hashlib.sha256()
     for k in sorted(sd):
-        digest.update(sd[k].detach().float().cpu().numpy().tobytes())
+        if k in names:        # parameters (fp32 masters); BatchNorm's running statistics are per rank by design
+            digest.update(sd[k].detach().float().cpu().numpy().tobytes())
     print("RANKLINE " + json.dumps({"rank": rank, "mode": mode, "losses": losses, "digest": digest.hexdigest(),
                                     "stats": stats}), flush=True)
     dist.barrier()
