@@ -170,6 +170,139 @@ __global__ __launch_bounds__(kGlueThreads) void column_finish_kernel(const float
   }
 }
 
+// ---- multi-tensor forms of the two reductions above -------------------------------------------------------------------
+// A Conformer iteration has 23 Linear layers (model_conformer.py:19-41, 98-127), a ResNet50-Conformer one 43: their
+// backward passes issued 3 latency-sized launches each (chunk sum of the split-K weight gradient, column partials +
+// finish of the bias gradient): 69 launches, 455 us of a 5.1 ms iteration, for ~40 MB of reads
+// (profiles/r02_conformer_timed_region_stats.csv).  Nothing consumes a weight or bias gradient before the optimiser, so
+// the captured step queues the reductions during the backward pass and runs them here: ONE launch for every chunk sum,
+// ONE for every column sum, descriptors by value in the kernel arguments (the seld_multi_cast pattern).
+
+constexpr int kMultiSum = 64;        // descriptors per launch: 64 x 32 B
+constexpr int kMultiCol = 40;        // 40 x 56 B
+
+struct SumDesc {
+  const void* partial;
+  void* out;
+  long count;
+  int chunks;
+  int flags;                         // bit 0: partial is bf16, bit 1: out is bf16, bit 2: 8-wide (count % 8 == 0, aligned)
+};
+struct SumBatch { SumDesc d[kMultiSum]; };
+
+__global__ __launch_bounds__(kGlueThreads) void multi_sum_chunks_kernel(SumBatch b) {
+  const SumDesc& d = b.d[blockIdx.y];
+  const bool in_bf16 = d.flags & 1, out_bf16 = d.flags & 2, wide = d.flags & 4;
+  const long i0 = (static_cast<long>(blockIdx.x) * kGlueThreads + threadIdx.x) * 8;
+  if (i0 >= d.count) return;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+  for (int c = 0; c < d.chunks; ++c) {
+    const long base = static_cast<long>(c) * d.count + i0;
+    if (wide && in_bf16) {
+      const uint4 v = *reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(d.partial) + base);
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[2 * j] += __uint_as_float(w[j] << 16);
+        acc[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (i0 + j < d.count) acc[j] += load_as_float(d.partial, base + j, in_bf16);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (i0 + j < d.count) store_from_float(d.out, i0 + j, out_bf16, acc[j]);
+}
+
+struct ColDesc {
+  const void* g;                     // [rows][n_cols]
+  void* out;                         // [n_cols]
+  float* partial;                    // [row_blocks][n_cols] scratch
+  unsigned* counters;                // [col_blocks], zero on entry, zero again on exit
+  int rows, n_cols;
+  int row_blocks, rows_per_block;
+  int first_item;                    // index of this matrix's first (column block, row block) work item
+  int flags;                         // bit 0: g is bf16, bit 1: out is bf16
+};
+struct ColBatch { ColDesc d[kMultiCol]; int n; };
+
+// One workgroup per (matrix, 256-column block, row block): partial column sums of its slab exactly as
+// column_partials_kernel forms them; the workgroup that finishes LAST for a column block adds the row blocks in index
+// order (whoever it is: the result does not depend on the arrival order) and resets the counter.
+__global__ __launch_bounds__(kGlueThreads) void multi_column_sums_kernel(ColBatch b) {
+  __shared__ float red[8][257];
+  __shared__ int last_flag;
+  const int tid = threadIdx.x;
+  int t = 0;
+  while (t + 1 < b.n && static_cast<int>(blockIdx.x) >= b.d[t + 1].first_item) ++t;      // uniform
+  const ColDesc& d = b.d[t];
+  const int item = static_cast<int>(blockIdx.x) - d.first_item;
+  const int col_block = item / d.row_blocks, row_block = item - col_block * d.row_blocks;
+  const bool in_bf16 = d.flags & 1, out_bf16 = d.flags & 2;
+  const int cg = tid & 31, slot = tid >> 5;
+  const int col0 = col_block * 256 + cg * 8;
+  const long r0 = static_cast<long>(row_block) * d.rows_per_block;
+  const long r1 = r0 + d.rows_per_block < d.rows ? r0 + d.rows_per_block : d.rows;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+  if (col0 < d.n_cols) {
+    auto add_row = [&](long r) {
+      const long base = r * d.n_cols + col0;
+      if (in_bf16) {
+        const uint4 v = *reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(d.g) + base);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[2 * j] += __uint_as_float(w[j] << 16);
+          acc[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+        }
+      } else {
+        const float4* q = reinterpret_cast<const float4*>(static_cast<const float*>(d.g) + base);
+        const float4 a = q[0], c = q[1];
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+        acc[4] += c.x; acc[5] += c.y; acc[6] += c.z; acc[7] += c.w;
+      }
+    };
+    long r = r0 + slot;
+    for (; r + 24 < r1; r += 32) {
+      add_row(r);
+      add_row(r + 8);
+      add_row(r + 16);
+      add_row(r + 24);
+    }
+    for (; r < r1; r += 8) add_row(r);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[slot][cg * 8 + j] = acc[j];
+  __syncthreads();
+  const int col = col_block * 256 + tid;
+  if (col < d.n_cols) {
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum += red[k][tid];
+    d.partial[static_cast<long>(row_block) * d.n_cols + col] = sum;
+  }
+  __threadfence();                                   // this workgroup's partial row is visible device-wide ...
+  __syncthreads();
+  if (tid == 0) last_flag = atomicAdd(d.counters + col_block, 1u) == static_cast<unsigned>(d.row_blocks - 1);
+  __syncthreads();
+  if (!last_flag) return;                            // ... before it counts as arrived
+  __threadfence();
+  if (col < d.n_cols) {
+    float total = 0.0f;                              // device-scope loads: the rows were written by other workgroups (other XCDs' L2)
+    for (int y = 0; y < d.row_blocks; ++y)
+      total += __hip_atomic_load(d.partial + static_cast<long>(y) * d.n_cols + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    store_from_float(d.out, col, out_bf16, total);
+  }
+  if (tid == 0) d.counters[col_block] = 0u;          // ready for the next launch (graph replay)
+}
+
 // dW_hh[d][g][u][k] from the two wasteful-but-well-shaped products the host forms (seld_gru._BiGRULayer.backward):
 //   p_gi[c][d][g][u][d'][k] = chunk c of  dgi^T h_prev      (g = 0..2; only d' == d and g < 2 are wanted)
 //   p_n [c][d][u][d'][k]    = chunk c of  (da_n r)^T h_prev (only d' == d)
@@ -287,6 +420,90 @@ int seld_column_sums(const void* g, int in_is_bf16, int64_t rows, int64_t n_cols
   hipLaunchKernelGGL(column_finish_kernel, dim3(static_cast<unsigned>((n_cols + 15) / 16)), dim3(kGlueThreads), 0, stream,
                      partial, static_cast<int>(rb), static_cast<int>(n_cols), out, out_is_bf16);
   SELD_HIP_TRY(hipGetLastError());
+  return kOk;
+}
+
+int seld_multi_sum_chunks(const void* const* partial, void* const* out, const int64_t* counts, const int32_t* chunks,
+                          const int32_t* flags, int count, void* stream_) {
+  using namespace seld;
+  if (!current_state()) return kErrNotInitialised;
+  if (count < 0) return fail(kErrInvalidArgument, "seld_multi_sum_chunks: negative count");
+  if (count == 0) return kOk;
+  if (!partial || !out || !counts || !chunks || !flags) return fail(kErrInvalidArgument, "seld_multi_sum_chunks: null pointer");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  for (int first = 0; first < count; first += kMultiSum) {
+    SumBatch b;
+    const int here = count - first < kMultiSum ? count - first : kMultiSum;
+    long longest = 0;
+    for (int i = 0; i < here; ++i) {
+      const int k = first + i;
+      if (counts[k] <= 0 || chunks[k] <= 0 || !partial[k] || !out[k])
+        return fail(kErrInvalidArgument, "seld_multi_sum_chunks: bad descriptor");
+      int f = flags[k] & 3;
+      if ((f & 1) && counts[k] % 8 == 0 && (reinterpret_cast<uintptr_t>(partial[k]) & 15) == 0) f |= 4;
+      b.d[i] = SumDesc{partial[k], out[k], static_cast<long>(counts[k]), chunks[k], f};
+      if (counts[k] > longest) longest = counts[k];
+    }
+    const long threads = (longest + 7) / 8;
+    const dim3 grid(static_cast<unsigned>((threads + kGlueThreads - 1) / kGlueThreads), static_cast<unsigned>(here));
+    hipLaunchKernelGGL(multi_sum_chunks_kernel, grid, dim3(kGlueThreads), 0, stream, b);
+  }
+  SELD_HIP_TRY(hipGetLastError());
+  return kOk;
+}
+
+int seld_multi_column_sums(const void* const* g, void* const* out, const int64_t* rows, const int64_t* n_cols,
+                           const int32_t* flags, int count, float* partial, int64_t partial_floats, uint32_t* counters,
+                           int64_t n_counters, void* stream_) {
+  using namespace seld;
+  if (!current_state()) return kErrNotInitialised;
+  if (count < 0) return fail(kErrInvalidArgument, "seld_multi_column_sums: negative count");
+  if (count == 0) return kOk;
+  if (!g || !out || !rows || !n_cols || !flags || !partial || !counters)
+    return fail(kErrInvalidArgument, "seld_multi_column_sums: null pointer");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  long used_floats = 0, used_counters = 0;
+  for (int first = 0; first < count; first += kMultiCol) {
+    ColBatch b;
+    const int here = count - first < kMultiCol ? count - first : kMultiCol;
+    int items = 0;
+    for (int i = 0; i < here; ++i) {
+      const int k = first + i;
+      if (rows[k] <= 0 || n_cols[k] <= 0 || rows[k] >= (1L << 31) || n_cols[k] >= (1L << 31) || !g[k] || !out[k])
+        return fail(kErrInvalidArgument, "seld_multi_column_sums: bad descriptor");
+      if (n_cols[k] % 8 != 0 || (reinterpret_cast<uintptr_t>(g[k]) & 15) != 0)
+        return fail(kErrUnsupported, "seld_multi_column_sums: the column count must be a multiple of 8 and the matrix 16-byte aligned");
+      const long rb = seld_column_sums_blocks(rows[k], n_cols[k]);
+      const long col_blocks = (n_cols[k] + 255) / 256;
+      if (used_floats + rb * n_cols[k] > partial_floats || used_counters + col_blocks > n_counters)
+        return fail(kErrInvalidArgument, "seld_multi_column_sums: scratch too small (seld_multi_column_sums_scratch)");
+      b.d[i] = ColDesc{g[k], out[k], partial + used_floats, counters + used_counters, static_cast<int>(rows[k]),
+                       static_cast<int>(n_cols[k]), static_cast<int>(rb), static_cast<int>((rows[k] + rb - 1) / rb), items,
+                       flags[k] & 3};
+      used_floats += rb * n_cols[k];
+      used_counters += col_blocks;
+      items += static_cast<int>(col_blocks * rb);
+    }
+    b.n = here;
+    hipLaunchKernelGGL(multi_column_sums_kernel, dim3(static_cast<unsigned>(items)), dim3(kGlueThreads), 0, stream, b);
+  }
+  SELD_HIP_TRY(hipGetLastError());
+  return kOk;
+}
+
+int seld_multi_column_sums_scratch(const int64_t* rows, const int64_t* n_cols, int count, int64_t* partial_floats,
+                                   int64_t* n_counters) {
+  using namespace seld;
+  if (count < 0 || (count > 0 && (!rows || !n_cols)) || !partial_floats || !n_counters)
+    return fail(kErrInvalidArgument, "seld_multi_column_sums_scratch: bad argument");
+  long f = 0, c = 0;
+  for (int k = 0; k < count; ++k) {
+    if (rows[k] <= 0 || n_cols[k] <= 0) return fail(kErrInvalidArgument, "seld_multi_column_sums_scratch: bad extent");
+    f += seld_column_sums_blocks(rows[k], n_cols[k]) * n_cols[k];
+    c += (n_cols[k] + 255) / 256;
+  }
+  *partial_floats = f;
+  *n_counters = c;
   return kOk;
 }
 

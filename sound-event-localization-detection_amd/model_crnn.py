@@ -51,6 +51,8 @@ class _Conv3x3(torch.autograd.Function):
                     wt = seld_native.conv_weight_flip_transpose(wc)                 # one launch (flip + copy are two)
                 else:
                     wt = wc.transpose(0, 1).flip(2, 3).contiguous(memory_format=torch.channels_last)
+                import seld_overlap
+                seld_overlap.release_held(dy.device)      # (wgrad_order "late": the previous block's weight gradient)
                 dx = F.conv2d(dy, wt, padding=1)
                 if dx.dtype != x_dtype:
                     dx = dx.to(x_dtype)
@@ -62,7 +64,7 @@ class _Conv3x3(torch.autograd.Function):
                 def job():
                     dw.copy_(torch.ops.aten.convolution_backward(dy, xc, wc, None, (1, 1), (1, 1), (1, 1), False, (0, 0),
                                                                  1, (False, True, False))[1])
-                seld_overlap.launch_now(dy.device, [dy, xc, wc, dw], job, last_of_stage=ctx.after_cut, outputs=[dw])
+                seld_overlap.launch_now(dy.device, [dy, xc, wc, dw], job, last_of_stage=ctx.after_cut, outputs=[dw], hold=True)
                 return dx, dw.view_as(dw)          # a fresh alias: autograd takes it over instead of cloning (seld_overlap)
             dw = torch.ops.aten.convolution_backward(dy, xc, wc, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
                                                      (False, True, False))[1]

@@ -205,6 +205,7 @@ class GraphedTrainStep:
         self.autocast = autocast if autocast is not None else nullcontext
         self.use_graphs = bool(use_graphs) and device.type == "cuda"
         self.wgrad_side = os.environ.get("SELD_WGRAD_SIDE", "1") != "0"     # developer switch for A/B runs
+        self.batch_reductions = os.environ.get("SELD_BATCH_REDUCTIONS", "1") != "0"      # developer switch for A/B runs
         self.params = [p for p in _unwrap(model).parameters() if p.requires_grad]
         self.exchange = world > 1 or split                       # flat buffers and separate graphs
         self.staged = self.exchange and bool(overlap_allreduce) and os.environ.get("SELD_OVERLAP_ALLREDUCE", "1") != "0"
@@ -249,15 +250,25 @@ class GraphedTrainStep:
         if side:
             seld_overlap.conv_wgrad_side = True
             seld_overlap.carry = not last
+        batching = self.device.type == "cuda" and self.batch_reductions
+        if batching:
+            import seld_linear
+            seld_linear.begin_batch()        # the Linears' chunk / column sums: one multi-tensor launch each, below
         try:
             if k > 0 and side:
                 seld_overlap.launch_carried(self.device)      # weight gradients the previous stage handed over
             torch.autograd.backward(root, grad)
+        except BaseException:
+            if batching:
+                seld_linear.abandon_batch()
+            raise
         finally:
             if side:
                 seld_overlap.conv_wgrad_side = False
                 seld_overlap.carry = False
                 seld_overlap.join(self.device)           # weight gradients produced on the side streams are complete
+        if batching:
+            seld_linear.flush_batch()
         if last:
             self._cuts = []
         if self.flat is not None:

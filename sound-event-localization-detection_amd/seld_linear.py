@@ -15,8 +15,44 @@ import seld_overlap
 
 enabled = True
 
+# ---- reductions queued during a captured step's backward pass ---------------------------------------------------------
+# Every Linear's backward ends in two latency-sized reductions (the chunk sum of the split-K weight gradient, the column
+# sum behind the bias gradient): 23 Linears per Conformer iteration, 43 per ResNet50-Conformer one -- 69 / 129 launches of
+# ~6 us for a few MB each.  Nothing consumes a weight or bias gradient before the optimiser, so while a batch is open
+# (``begin_batch``: seld_graph.GraphedTrainStep around its backward pass; never under DistributedDataParallel, whose reducer
+# copies gradients as autograd delivers them) they are queued and ``flush_batch`` runs ONE multi-tensor launch of each kind
+# (csrc/glue.hip).  The queued outputs are handed to autograd as fresh aliases: autograd clones a gradient tensor that
+# is referenced elsewhere -- here, before it has been filled.
+_batch = None
 
-def tall_product(a, c, out_dtype=torch.float32, out=None):
+
+def begin_batch():
+    global _batch
+    _batch = {"sums": [], "cols": []}
+
+
+def flush_batch(close=True):
+    """Run the queued reductions on the current stream; ``close``: stop queueing."""
+    global _batch
+    batch = _batch
+    if close:
+        _batch = None
+    elif batch is not None:
+        _batch = {"sums": [], "cols": []}
+    if batch is None:
+        return 0
+    import seld_native
+    seld_native.multi_sum_chunks(batch["sums"])
+    seld_native.multi_column_sums(batch["cols"])
+    return len(batch["sums"]) + len(batch["cols"])
+
+
+def abandon_batch():
+    global _batch
+    _batch = None
+
+
+def tall_product(a, c, out_dtype=torch.float32, out=None, queue=False):
     """a^T c for tall operands (a [N, G], c [N, K]) -> [G, K] in ``out_dtype``.  Row strides may be anything (column
     stride 1).  The library's transposed-A GEMM with an 8000-row reduction runs at a fraction of its usual rate, the
     more so the smaller the output (measured, bf16, N = 8000, tools/bench_tall_product.py: 9072 x 512 125 us as one
@@ -36,6 +72,9 @@ def tall_product(a, c, out_dtype=torch.float32, out=None):
         out = torch.empty((g, k), dtype=out_dtype, device=a.device)
     if partial.is_cuda and out.is_contiguous() and partial.dtype in (torch.float32, torch.bfloat16) \
             and out.dtype in (torch.float32, torch.bfloat16):
+        if queue and _batch is not None:
+            _batch["sums"].append((partial, out))            # filled by flush_batch (``queue``: the caller allows it)
+            return out
         import seld_native
         return seld_native.sum_chunks(partial, out)          # one launch (torch.sum(out=) is fill + reduce + copy)
     return torch.sum(partial, dim=0, dtype=out.dtype, out=out)
@@ -61,13 +100,16 @@ def tall_chunks(a, c, chunks=None):
     return torch.bmm(av, cv)
 
 
-def column_sum(g2, out):
+def column_sum(g2, out, queue=False):
     """out[n] = sum_r g2[r, n] with fp32 accumulation: the bias gradient.  csrc/glue.hip (two launches, ~1000 workgroups
     streaming the matrix) where it applies -- the framework's reduction takes 16 - 36 us for these 8000-row shapes whatever
     their width, and a Conformer iteration has 19 of them."""
     import os
     import seld_native
     if os.environ.get("SELD_COLUMN_SUMS", "1") != "0" and seld_native.column_sums_supported(g2, out):      # developer A/B switch
+        if queue and _batch is not None:
+            _batch["cols"].append((g2, out))
+            return out
         return seld_native.column_sums(g2, out)
     return torch.sum(g2, dim=0, dtype=out.dtype, out=out)
 
@@ -113,8 +155,12 @@ class _Linear(torch.autograd.Function):
 
                 seld_overlap.submit(grad.device, [t for t in (g2, x2, dw, db) if t is not None], job)
             else:
-                dw = tall_product(g2, x2, out_dtype=ctx.w_dtype) if want_w else None
-                db = column_sum(g2, torch.empty((g2.shape[1],), dtype=ctx.b_dtype, device=grad.device)) if want_b else None
+                dw = tall_product(g2, x2, out_dtype=ctx.w_dtype, queue=True) if want_w else None
+                db = column_sum(g2, torch.empty((g2.shape[1],), dtype=ctx.b_dtype, device=grad.device), queue=True) \
+                    if want_b else None
+                if _batch is not None:                      # possibly queued: fresh aliases for autograd (see above)
+                    dw = dw.view_as(dw) if dw is not None else None
+                    db = db.view_as(db) if db is not None else None
         if dx is not None and dx.dtype != ctx.in_dtype:
             dx = dx.to(ctx.in_dtype)
         return dx, dw, db, None

@@ -79,6 +79,10 @@ def _declare(lib):
     lib.seld_sum_chunks.argtypes = [_ptr, _int, _i64, _i64, _ptr, _int, _ptr]
     lib.seld_gru_dwhh_finish.argtypes = [_ptr, _ptr, _int, _i64, _i64, _ptr, _int, _ptr]
     lib.seld_column_sums.argtypes = [_ptr, _int, _i64, _i64, _ptr, _ptr, _int, _ptr]
+    _pp, _pi64, _pi32 = ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32)
+    lib.seld_multi_sum_chunks.argtypes = [_pp, _pp, _pi64, _pi32, _pi32, _int, _ptr]
+    lib.seld_multi_column_sums_scratch.argtypes = [_pi64, _pi64, _int, _pi64, _pi64]
+    lib.seld_multi_column_sums.argtypes = [_pp, _pp, _pi64, _pi64, _pi32, _int, _ptr, _i64, _ptr, _i64, _ptr]
     lib.seld_column_sums_blocks.argtypes = [_i64, _i64]
     lib.seld_column_sums_blocks.restype = ctypes.c_int64
     lib.seld_conv_weight_flip_transpose.argtypes = [_ptr, _int, _i64, _i64, _ptr, _ptr]
@@ -835,6 +839,65 @@ def column_sums(g: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         check(lib.seld_column_sums(_p(g), _is_bf16(g), rows, n, _p(partial), _p(out), _is_bf16(out), _stream_ptr(g.device)),
               "seld_column_sums")
     return out
+
+
+def multi_sum_chunks(pairs) -> None:
+    """``out[...] = partial.sum(dim=0)`` for every (partial [chunks, ...], out [...]) pair in ONE launch per 64 pairs
+    (csrc/glue.hip multi_sum_chunks_kernel; fp32 accumulation in chunk order, like ``sum_chunks``)."""
+    pairs = list(pairs)
+    if not pairs:
+        return
+    for partial, out in pairs:
+        if not (partial.is_cuda and partial.is_contiguous() and out.is_contiguous()
+                and tuple(partial.shape[1:]) == tuple(out.shape) and partial.dtype in (torch.float32, torch.bfloat16)
+                and out.dtype in (torch.float32, torch.bfloat16)):
+            raise SeldNativeError("multi_sum_chunks: partial [chunks, ...] / out [...] contiguous bf16 or fp32")
+    n = len(pairs)
+    src = (ctypes.c_void_p * n)(*[p.data_ptr() for p, _ in pairs])
+    dst = (ctypes.c_void_p * n)(*[o.data_ptr() for _, o in pairs])
+    counts = (ctypes.c_int64 * n)(*[o.numel() for _, o in pairs])
+    chunks = (ctypes.c_int32 * n)(*[p.shape[0] for p, _ in pairs])
+    flags = (ctypes.c_int32 * n)(*[_is_bf16(p) | (_is_bf16(o) << 1) for p, o in pairs])
+    device = pairs[0][1].device
+    with _device_guard(ensure_init(device)):
+        check(load_library().seld_multi_sum_chunks(src, dst, counts, chunks, flags, n, _stream_ptr(device)),
+              "seld_multi_sum_chunks")
+
+
+_column_scratch = {}      # device index -> (partial fp32, counters uint32 as int32 storage): grown on demand, counters zero
+
+
+def multi_column_sums(pairs) -> None:
+    """``out[n] = sum_r g[r, n]`` for every (g [rows, N], out [N]) pair in ONE launch per 40 pairs (csrc/glue.hip
+    multi_column_sums_kernel: the last workgroup of a column block adds the row blocks in index order)."""
+    pairs = list(pairs)
+    if not pairs:
+        return
+    for g, out in pairs:
+        if not column_sums_supported(g, out):
+            raise SeldNativeError("multi_column_sums: g [rows, N] contiguous bf16 / fp32 with N % 8 == 0, out [N] contiguous")
+    lib = load_library()
+    n = len(pairs)
+    src = (ctypes.c_void_p * n)(*[g.data_ptr() for g, _ in pairs])
+    dst = (ctypes.c_void_p * n)(*[o.data_ptr() for _, o in pairs])
+    rows = (ctypes.c_int64 * n)(*[g.shape[0] for g, _ in pairs])
+    cols = (ctypes.c_int64 * n)(*[g.shape[1] for g, _ in pairs])
+    flags = (ctypes.c_int32 * n)(*[_is_bf16(g) | (_is_bf16(o) << 1) for g, o in pairs])
+    need_f, need_c = ctypes.c_int64(0), ctypes.c_int64(0)
+    check(lib.seld_multi_column_sums_scratch(rows, cols, n, ctypes.byref(need_f), ctypes.byref(need_c)),
+          "seld_multi_column_sums_scratch")
+    device = pairs[0][0].device
+    index = ensure_init(device)
+    scratch = _column_scratch.get(index)
+    if scratch is None or scratch[0].numel() < need_f.value or scratch[1].numel() < need_c.value:
+        if torch.cuda.is_current_stream_capturing():
+            raise SeldNativeError("multi_column_sums: the scratch must be sized by an eager call before a graph capture")
+        scratch = (torch.empty(max(need_f.value, 1 << 20), dtype=torch.float32, device=device),
+                   torch.zeros(max(need_c.value, 4096), dtype=torch.int32, device=device))
+        _column_scratch[index] = scratch
+    with _device_guard(index):
+        check(lib.seld_multi_column_sums(src, dst, rows, cols, flags, n, _p(scratch[0]), scratch[0].numel(), _p(scratch[1]),
+                                         scratch[1].numel(), _stream_ptr(device)), "seld_multi_column_sums")
 
 
 def gru_dwhh_finish(p_gi: torch.Tensor, p_n: torch.Tensor, out: torch.Tensor) -> torch.Tensor:

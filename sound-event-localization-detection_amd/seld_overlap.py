@@ -115,9 +115,35 @@ conv_wgrad_side = False
 # of the earlier stage's all-reduce bucket).
 carry = False
 _carried = []
+# Developer A/B switch: "late" holds a convolution's weight gradient back until the NEXT convolution's
+# backward, so that it runs beside that block's data-gradient convolution (both matrix-core bound) and the HBM-bound
+# conv-tail kernels in between run alone; default: started as soon as it is computable (beside the next tail).
+wgrad_order = os.environ.get("SELD_WGRAD_ORDER", "early")
+_held = []
 
 
-def launch_now(device, tensors, job, last_of_stage=False, outputs=()):
+def release_held(device):
+    """Start the weight-gradient jobs held back by ``wgrad_order = 'late'`` (called right before a data-gradient
+    convolution is enqueued, and by ``join``)."""
+    jobs = list(_held)
+    del _held[:]
+    for dev, tensors, job in jobs:
+        _run_on_side(dev, tensors, job)
+    return len(jobs)
+
+
+def _run_on_side(device, tensors, job):
+    main = torch.cuda.current_stream(device)
+    side = side_stream(device, 1)
+    side.wait_stream(main)
+    _mark(device, 1)
+    with torch.cuda.stream(side):
+        job()
+    for t in tensors:
+        t.record_stream(side)
+
+
+def launch_now(device, tensors, job, last_of_stage=False, outputs=(), hold=False):
     """Run ``job()`` on side stream 1 behind what the main stream holds now; ``join`` must follow before the results
     are read on the main stream.  ``last_of_stage``: the caller is the last node of a backward stage when a cut follows
     it (GRU layer 0; the convolution that consumes a ``seld_cut.boundary`` leaf) -- carried over while ``carry`` is set.
@@ -128,14 +154,10 @@ def launch_now(device, tensors, job, last_of_stage=False, outputs=()):
     if carry and last_of_stage:
         _carried.append((device, tensors, job, tuple(outputs)))
         return
-    main = torch.cuda.current_stream(device)
-    side = side_stream(device, 1)
-    side.wait_stream(main)
-    _mark(device, 1)
-    with torch.cuda.stream(side):
-        job()
-    for t in tensors:
-        t.record_stream(side)
+    if wgrad_order == "late" and hold:
+        _held.append((device, tensors, job))
+        return
+    _run_on_side(device, tensors, job)
 
 
 def launch_carried(device):
@@ -165,6 +187,7 @@ def carried_outputs():
 def join(device):
     """The main stream waits for everything queued on the side streams (pending jobs are launched first)."""
     launch_pending(device)
+    release_held(device)
     _wait(device, 0)
     _wait(device, 1)
 

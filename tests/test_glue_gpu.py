@@ -108,3 +108,64 @@ def test_conv3x3_data_gradient_still_matches_autograd(gpu_device):
     torch.nn.functional.conv2d(x, w, padding=1).backward(go)
     assert (dx - x.grad).abs().max().item() <= 1e-4 * x.grad.abs().max().item()
     assert (dw - w.grad).abs().max().item() <= 1e-4 * w.grad.abs().max().item()
+
+
+def test_multi_tensor_reductions_equal_the_single_ones(gpu_device):
+    """``multi_sum_chunks`` / ``multi_column_sums`` (one launch for every queued reduction of a backward pass) against
+    ``sum_chunks`` / ``column_sums`` on the same tensors: same summation order, so the results must be IDENTICAL; run
+    twice (the column kernel's arrival counters must come back to zero) and with more pairs than one launch holds."""
+    import seld_native
+    g = torch.Generator().manual_seed(5)
+    shapes = [(5, 9072, 512), (8, 512, 512), (3, 7, 5), (1, 33, 3), (8, 256, 1024), (2, 1024, 256)] * 12     # 72 > 64
+    sums = []
+    for i, shape in enumerate(shapes):
+        in_dtype = torch.bfloat16 if i % 3 else torch.float32
+        out_dtype = torch.float32 if i % 2 else torch.bfloat16
+        partial = torch.randn(*shape, generator=g).to(in_dtype).to(gpu_device)
+        sums.append((partial, torch.empty(shape[1:], dtype=out_dtype, device=gpu_device)))
+    cols = []
+    for i, (rows, n) in enumerate([(8000, 256), (8000, 9072), (8000, 1024), (750, 512), (3, 8), (8000, 512)] * 8):    # 48 > 40
+        in_dtype = torch.bfloat16 if i % 3 else torch.float32
+        out_dtype = torch.bfloat16 if i % 2 else torch.float32
+        m = (torch.randn(rows, n, generator=g) * 0.3).to(in_dtype).to(gpu_device)
+        cols.append((m, torch.empty(n, dtype=out_dtype, device=gpu_device)))
+    for _ in range(2):
+        for _, out in sums + cols:
+            out.fill_(float("nan"))
+        seld_native.multi_sum_chunks(sums)
+        seld_native.multi_column_sums(cols)
+        for partial, out in sums:
+            assert torch.equal(out, seld_native.sum_chunks(partial, torch.empty_like(out)))
+        for m, out in cols:
+            assert torch.equal(out, seld_native.column_sums(m, torch.empty_like(out)))
+            want = m.double().sum(dim=0)
+            tol = (2.0 ** -8 if out.dtype == torch.bfloat16 else 1e-5) * (want.abs() + 1.0)
+            assert ((out.double() - want).abs() <= tol).all()
+
+
+def test_linear_backward_queues_its_reductions_inside_a_batch(gpu_device):
+    """seld_linear.begin_batch / flush_batch (what the captured step does around its backward pass): the weight and bias
+    gradients of SeldLinear layers are the same tensors' worth of numbers as without the batch, bit for bit."""
+    import seld_linear
+    from seld_linear import SeldLinear
+    torch.manual_seed(0)
+    layers = [SeldLinear(256, 1024), SeldLinear(1024, 256), SeldLinear(256, 9072)]
+    for m in layers:
+        m.to(gpu_device).to(torch.bfloat16)
+    x = torch.randn(8000, 256, device=gpu_device).to(torch.bfloat16)
+
+    def run(batched):
+        for m in layers:
+            m.weight.grad = m.bias.grad = None
+        y = layers[2](layers[1](torch.relu(layers[0](x))))
+        if batched:
+            seld_linear.begin_batch()
+        y.float().square().mean().backward()
+        if batched:
+            assert seld_linear.flush_batch() == 6
+        return [p.grad.clone() for m in layers for p in (m.weight, m.bias)]
+
+    plain, queued = run(False), run(True)
+    assert seld_linear._batch is None
+    for a, b in zip(plain, queued):
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b)
