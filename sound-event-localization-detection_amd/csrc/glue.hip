@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kGlueThreads) void column_finish_kernel(const float
 // the captured step queues the reductions during the backward pass and runs them here: ONE launch for every chunk sum,
 // ONE for every column sum, descriptors by value in the kernel arguments (the seld_multi_cast pattern).
 
-constexpr int kMultiSum = 64;        // descriptors per launch: 64 x 32 B
+constexpr int kMultiSum = 64;        // descriptors per launch: 64 x 40 B
 constexpr int kMultiCol = 40;        // 40 x 56 B
 
 struct SumDesc {
@@ -187,13 +187,17 @@ struct SumDesc {
   long count;
   int chunks;
   int flags;                         // bit 0: partial is bf16, bit 1: out is bf16, bit 2: 8-wide (count % 8 == 0, aligned)
+  int first_block;                   // index of this tensor's first workgroup (work list: no empty workgroups)
+  int pad;
 };
-struct SumBatch { SumDesc d[kMultiSum]; };
+struct SumBatch { SumDesc d[kMultiSum]; int n; };
 
 __global__ __launch_bounds__(kGlueThreads) void multi_sum_chunks_kernel(SumBatch b) {
-  const SumDesc& d = b.d[blockIdx.y];
+  int t = 0;
+  while (t + 1 < b.n && static_cast<int>(blockIdx.x) >= b.d[t + 1].first_block) ++t;      // uniform
+  const SumDesc& d = b.d[t];
   const bool in_bf16 = d.flags & 1, out_bf16 = d.flags & 2, wide = d.flags & 4;
-  const long i0 = (static_cast<long>(blockIdx.x) * kGlueThreads + threadIdx.x) * 8;
+  const long i0 = (static_cast<long>(static_cast<int>(blockIdx.x) - d.first_block) * kGlueThreads + threadIdx.x) * 8;
   if (i0 >= d.count) return;
   float acc[8];
 #pragma unroll
@@ -295,8 +299,19 @@ __global__ __launch_bounds__(kGlueThreads) void multi_column_sums_kernel(ColBatc
   if (!last_flag) return;                            // ... before it counts as arrived
   __threadfence();
   if (col < d.n_cols) {
-    float total = 0.0f;                              // device-scope loads: the rows were written by other workgroups (other XCDs' L2)
-    for (int y = 0; y < d.row_blocks; ++y)
+    // device-scope loads (the rows were written by other workgroups, possibly behind another XCD's L2), eight in flight,
+    // added in row-block order
+    float total = 0.0f;
+    int y = 0;
+    for (; y + 8 <= d.row_blocks; y += 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        v[k] = __hip_atomic_load(d.partial + static_cast<long>(y + k) * d.n_cols + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) total += v[k];
+    }
+    for (; y < d.row_blocks; ++y)
       total += __hip_atomic_load(d.partial + static_cast<long>(y) * d.n_cols + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     store_from_float(d.out, col, out_bf16, total);
   }
@@ -423,6 +438,15 @@ int seld_column_sums(const void* g, int in_is_bf16, int64_t rows, int64_t n_cols
   return kOk;
 }
 
+// Row blocks of one matrix inside a multi-tensor launch: a quarter of the stand-alone kernel's (the launch as a whole
+// fills the chip, and the finishing workgroup of a column block reads one partial row per row block).
+static long multi_column_row_blocks(int64_t rows, int64_t n_cols) {
+  long rb = seld_column_sums_blocks(rows, n_cols) / 4;
+  if (rb < 8) rb = 8;
+  if (rb > rows) rb = rows;
+  return rb;
+}
+
 int seld_multi_sum_chunks(const void* const* partial, void* const* out, const int64_t* counts, const int32_t* chunks,
                           const int32_t* flags, int count, void* stream_) {
   using namespace seld;
@@ -434,19 +458,19 @@ int seld_multi_sum_chunks(const void* const* partial, void* const* out, const in
   for (int first = 0; first < count; first += kMultiSum) {
     SumBatch b;
     const int here = count - first < kMultiSum ? count - first : kMultiSum;
-    long longest = 0;
+    long blocks = 0;
     for (int i = 0; i < here; ++i) {
       const int k = first + i;
       if (counts[k] <= 0 || chunks[k] <= 0 || !partial[k] || !out[k])
         return fail(kErrInvalidArgument, "seld_multi_sum_chunks: bad descriptor");
       int f = flags[k] & 3;
       if ((f & 1) && counts[k] % 8 == 0 && (reinterpret_cast<uintptr_t>(partial[k]) & 15) == 0) f |= 4;
-      b.d[i] = SumDesc{partial[k], out[k], static_cast<long>(counts[k]), chunks[k], f};
-      if (counts[k] > longest) longest = counts[k];
+      b.d[i] = SumDesc{partial[k], out[k], static_cast<long>(counts[k]), chunks[k], f, static_cast<int>(blocks), 0};
+      blocks += ((counts[k] + 7) / 8 + kGlueThreads - 1) / kGlueThreads;
+      if (blocks >= (1L << 31)) return fail(kErrUnsupported, "seld_multi_sum_chunks: too many elements for one launch");
     }
-    const long threads = (longest + 7) / 8;
-    const dim3 grid(static_cast<unsigned>((threads + kGlueThreads - 1) / kGlueThreads), static_cast<unsigned>(here));
-    hipLaunchKernelGGL(multi_sum_chunks_kernel, grid, dim3(kGlueThreads), 0, stream, b);
+    b.n = here;
+    hipLaunchKernelGGL(multi_sum_chunks_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kGlueThreads), 0, stream, b);
   }
   SELD_HIP_TRY(hipGetLastError());
   return kOk;
@@ -473,7 +497,7 @@ int seld_multi_column_sums(const void* const* g, void* const* out, const int64_t
         return fail(kErrInvalidArgument, "seld_multi_column_sums: bad descriptor");
       if (n_cols[k] % 8 != 0 || (reinterpret_cast<uintptr_t>(g[k]) & 15) != 0)
         return fail(kErrUnsupported, "seld_multi_column_sums: the column count must be a multiple of 8 and the matrix 16-byte aligned");
-      const long rb = seld_column_sums_blocks(rows[k], n_cols[k]);
+      const long rb = multi_column_row_blocks(rows[k], n_cols[k]);
       const long col_blocks = (n_cols[k] + 255) / 256;
       if (used_floats + rb * n_cols[k] > partial_floats || used_counters + col_blocks > n_counters)
         return fail(kErrInvalidArgument, "seld_multi_column_sums: scratch too small (seld_multi_column_sums_scratch)");
@@ -499,7 +523,7 @@ int seld_multi_column_sums_scratch(const int64_t* rows, const int64_t* n_cols, i
   long f = 0, c = 0;
   for (int k = 0; k < count; ++k) {
     if (rows[k] <= 0 || n_cols[k] <= 0) return fail(kErrInvalidArgument, "seld_multi_column_sums_scratch: bad extent");
-    f += seld_column_sums_blocks(rows[k], n_cols[k]) * n_cols[k];
+    f += multi_column_row_blocks(rows[k], n_cols[k]) * n_cols[k];
     c += (n_cols[k] + 255) / 256;
   }
   *partial_floats = f;

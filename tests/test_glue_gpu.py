@@ -112,7 +112,7 @@ def test_conv3x3_data_gradient_still_matches_autograd(gpu_device):
 
 def test_multi_tensor_reductions_equal_the_single_ones(gpu_device):
     """``multi_sum_chunks`` / ``multi_column_sums`` (one launch for every queued reduction of a backward pass) against
-    ``sum_chunks`` / ``column_sums`` on the same tensors: same summation order, so the results must be IDENTICAL; run
+    ``sum_chunks`` on the same tensors (same summation order: IDENTICAL) and a float64 column sum; run
     twice (the column kernel's arrival counters must come back to zero) and with more pairs than one launch holds."""
     import seld_native
     g = torch.Generator().manual_seed(5)
@@ -136,8 +136,7 @@ def test_multi_tensor_reductions_equal_the_single_ones(gpu_device):
         seld_native.multi_column_sums(cols)
         for partial, out in sums:
             assert torch.equal(out, seld_native.sum_chunks(partial, torch.empty_like(out)))
-        for m, out in cols:
-            assert torch.equal(out, seld_native.column_sums(m, torch.empty_like(out)))
+        for m, out in cols:                                # (row blocks added in a different fixed order than column_sums)
             want = m.double().sum(dim=0)
             tol = (2.0 ** -8 if out.dtype == torch.bfloat16 else 1e-5) * (want.abs() + 1.0)
             assert ((out.double() - want).abs() <= tol).all()
