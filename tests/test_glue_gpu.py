@@ -166,5 +166,9 @@ def test_linear_backward_queues_its_reductions_inside_a_batch(gpu_device):
 
     plain, queued = run(False), run(True)
     assert seld_linear._batch is None
-    for a, b in zip(plain, queued):
-        assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+    for i, (a, b) in enumerate(zip(plain, queued)):
+        assert torch.isfinite(a.float()).all()
+        if i % 2 == 0:                                     # weights: same chunk order
+            assert torch.equal(a, b)
+        else:                                              # biases: the row blocks are added in a different fixed order
+            assert (a.float() - b.float()).abs().max().item() <= 2.0 ** -7 * a.float().abs().max().item()
