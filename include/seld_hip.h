@@ -215,18 +215,14 @@ int seld_column_sums(const void* g, int in_is_bf16, int64_t rows, int64_t n_cols
 
 /* Multi-tensor forms of the two reductions above, for a backward pass that queues them (every nn.Linear of
  * model_conformer.py:19-41,98-127 / resnet50_model.py:80-91 contributes one of each; nothing reads a weight or bias
- * gradient before the optimiser of trainer.py:179): ONE launch per 64 chunk sums / per 40 column sums, descriptors by value.
- * flags[k]: bit 0 = the input is bf16, bit 1 = the output is bf16.
- * seld_multi_column_sums needs caller-owned scratch sized by seld_multi_column_sums_scratch: `partial` (fp32) and
- * `counters` (uint32, ZERO before the first call; every launch leaves them zero again).  The workgroup that finishes last
- * for a block of 256 columns adds the row blocks in index order: deterministic, same sums as seld_column_sums. */
+ * gradient before the optimiser of trainer.py:179): ONE launch per 64 chunk sums, TWO (row-block partials, fixed-order
+ * finish) per 40 column sums, descriptors by value.  flags[k]: bit 0 = the input is bf16, bit 1 = the output is bf16.
+ * seld_multi_column_sums needs caller-owned fp32 scratch `partial` sized by seld_multi_column_sums_scratch. */
 int seld_multi_sum_chunks(const void* const* partial, void* const* out, const int64_t* counts, const int32_t* chunks,
                           const int32_t* flags, int count, void* stream);
-int seld_multi_column_sums_scratch(const int64_t* rows, const int64_t* n_cols, int count, int64_t* partial_floats,
-                                   int64_t* n_counters);
+int seld_multi_column_sums_scratch(const int64_t* rows, const int64_t* n_cols, int count, int64_t* partial_floats);
 int seld_multi_column_sums(const void* const* g, void* const* out, const int64_t* rows, const int64_t* n_cols,
-                           const int32_t* flags, int count, float* partial, int64_t partial_floats, uint32_t* counters,
-                           int64_t n_counters, void* stream);
+                           const int32_t* flags, int count, float* partial, int64_t partial_floats, void* stream);
 
 /* dW_hh [2][3H][H] of nn.GRU from the two chunked products the host forms over both directions at once:
  * p_gi [chunks][2][3][H][2][H] = (da_r, da_z, da_n)^T h_prev, p_n [chunks][2][H][2][H] = (da_n r)^T h_prev; the blocks

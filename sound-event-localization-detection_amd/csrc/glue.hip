@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kGlueThreads) void column_finish_kernel(const float
 // finish of the bias gradient): 69 launches, 455 us of a 5.1 ms iteration, for ~40 MB of reads
 // (profiles/r02_conformer_timed_region_stats.csv).  Nothing consumes a weight or bias gradient before the optimiser, so
 // the captured step queues the reductions during the backward pass and runs them here: ONE launch for every chunk sum,
-// ONE for every column sum, descriptors by value in the kernel arguments (the seld_multi_cast pattern).
+// TWO (partials, finish) for every column sum, descriptors by value in the kernel arguments (the seld_multi_cast pattern).
 
 constexpr int kMultiSum = 64;        // descriptors per launch: 64 x 40 B
 constexpr int kMultiCol = 40;        // 40 x 56 B
@@ -227,27 +227,29 @@ struct ColDesc {
   const void* g;                     // [rows][n_cols]
   void* out;                         // [n_cols]
   float* partial;                    // [row_blocks][n_cols] scratch
-  unsigned* counters;                // [col_blocks], zero on entry, zero again on exit
   int rows, n_cols;
   int row_blocks, rows_per_block;
-  int first_item;                    // index of this matrix's first (column block, row block) work item
+  int first_item;                    // index of this matrix's first (column block, row block) work item (partials kernel)
+  int first_finish;                  // index of its first 16-column workgroup (finish kernel)
   int flags;                         // bit 0: g is bf16, bit 1: out is bf16
+  int pad;
 };
 struct ColBatch { ColDesc d[kMultiCol]; int n; };
 
-// One workgroup per (matrix, 256-column block, row block): partial column sums of its slab exactly as
-// column_partials_kernel forms them; the workgroup that finishes LAST for a column block adds the row blocks in index
-// order (whoever it is: the result does not depend on the arrival order) and resets the counter.
-__global__ __launch_bounds__(kGlueThreads) void multi_column_sums_kernel(ColBatch b) {
+// Stage 1, one workgroup per (matrix, 256-column block, row block): partial column sums of its slab exactly as
+// column_partials_kernel forms them.  Stage 2 (multi_column_finish_kernel, the kernel boundary makes the partial rows
+// visible: a device-scope fence inside one kernel costs an L2 write-back per workgroup on this multi-XCD chip -- the
+// single-kernel "last workgroup finishes" form was measured at 375 us for a Conformer's 23 matrices) adds the row blocks
+// in a fixed order, like column_finish_kernel.
+__global__ __launch_bounds__(kGlueThreads) void multi_column_partials_kernel(ColBatch b) {
   __shared__ float red[8][257];
-  __shared__ int last_flag;
   const int tid = threadIdx.x;
   int t = 0;
   while (t + 1 < b.n && static_cast<int>(blockIdx.x) >= b.d[t + 1].first_item) ++t;      // uniform
   const ColDesc& d = b.d[t];
   const int item = static_cast<int>(blockIdx.x) - d.first_item;
   const int col_block = item / d.row_blocks, row_block = item - col_block * d.row_blocks;
-  const bool in_bf16 = d.flags & 1, out_bf16 = d.flags & 2;
+  const bool in_bf16 = d.flags & 1;
   const int cg = tid & 31, slot = tid >> 5;
   const int col0 = col_block * 256 + cg * 8;
   const long r0 = static_cast<long>(row_block) * d.rows_per_block;
@@ -292,30 +294,27 @@ __global__ __launch_bounds__(kGlueThreads) void multi_column_sums_kernel(ColBatc
     for (int k = 0; k < 8; ++k) sum += red[k][tid];
     d.partial[static_cast<long>(row_block) * d.n_cols + col] = sum;
   }
-  __threadfence();                                   // this workgroup's partial row is visible device-wide ...
+}
+
+__global__ __launch_bounds__(kGlueThreads) void multi_column_finish_kernel(ColBatch b) {
+  __shared__ float red[16][17];
+  const int tid = threadIdx.x;
+  int t = 0;
+  while (t + 1 < b.n && static_cast<int>(blockIdx.x) >= b.d[t + 1].first_finish) ++t;    // uniform
+  const ColDesc& d = b.d[t];
+  const int c = tid & 15, slot = tid >> 4;
+  const int col = (static_cast<int>(blockIdx.x) - d.first_finish) * 16 + c;
+  float sum = 0.0f;
+  if (col < d.n_cols)
+    for (int y = slot; y < d.row_blocks; y += 16) sum += d.partial[static_cast<long>(y) * d.n_cols + col];
+  red[slot][c] = sum;
   __syncthreads();
-  if (tid == 0) last_flag = atomicAdd(d.counters + col_block, 1u) == static_cast<unsigned>(d.row_blocks - 1);
-  __syncthreads();
-  if (!last_flag) return;                            // ... before it counts as arrived
-  __threadfence();
-  if (col < d.n_cols) {
-    // device-scope loads (the rows were written by other workgroups, possibly behind another XCD's L2), eight in flight,
-    // added in row-block order
+  if (slot == 0 && col < d.n_cols) {
     float total = 0.0f;
-    int y = 0;
-    for (; y + 8 <= d.row_blocks; y += 8) {
-      float v[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-        v[k] = __hip_atomic_load(d.partial + static_cast<long>(y + k) * d.n_cols + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) total += v[k];
-    }
-    for (; y < d.row_blocks; ++y)
-      total += __hip_atomic_load(d.partial + static_cast<long>(y) * d.n_cols + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    store_from_float(d.out, col, out_bf16, total);
+    for (int k = 0; k < 16; ++k) total += red[k][c];
+    store_from_float(d.out, col, (d.flags & 2) != 0, total);
   }
-  if (tid == 0) d.counters[col_block] = 0u;          // ready for the next launch (graph replay)
 }
 
 // dW_hh[d][g][u][k] from the two wasteful-but-well-shaped products the host forms (seld_gru._BiGRULayer.backward):
@@ -438,10 +437,10 @@ int seld_column_sums(const void* g, int in_is_bf16, int64_t rows, int64_t n_cols
   return kOk;
 }
 
-// Row blocks of one matrix inside a multi-tensor launch: a quarter of the stand-alone kernel's (the launch as a whole
-// fills the chip, and the finishing workgroup of a column block reads one partial row per row block).
+// Row blocks of one matrix inside a multi-tensor launch: half of the stand-alone kernel's (the launch as a whole fills
+// the chip).
 static long multi_column_row_blocks(int64_t rows, int64_t n_cols) {
-  long rb = seld_column_sums_blocks(rows, n_cols) / 4;
+  long rb = seld_column_sums_blocks(rows, n_cols) / 2;
   if (rb < 8) rb = 8;
   if (rb > rows) rb = rows;
   return rb;
@@ -477,20 +476,19 @@ int seld_multi_sum_chunks(const void* const* partial, void* const* out, const in
 }
 
 int seld_multi_column_sums(const void* const* g, void* const* out, const int64_t* rows, const int64_t* n_cols,
-                           const int32_t* flags, int count, float* partial, int64_t partial_floats, uint32_t* counters,
-                           int64_t n_counters, void* stream_) {
+                           const int32_t* flags, int count, float* partial, int64_t partial_floats, void* stream_) {
   using namespace seld;
   if (!current_state()) return kErrNotInitialised;
   if (count < 0) return fail(kErrInvalidArgument, "seld_multi_column_sums: negative count");
   if (count == 0) return kOk;
-  if (!g || !out || !rows || !n_cols || !flags || !partial || !counters)
+  if (!g || !out || !rows || !n_cols || !flags || !partial)
     return fail(kErrInvalidArgument, "seld_multi_column_sums: null pointer");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  long used_floats = 0, used_counters = 0;
+  long used_floats = 0;
   for (int first = 0; first < count; first += kMultiCol) {
     ColBatch b;
     const int here = count - first < kMultiCol ? count - first : kMultiCol;
-    int items = 0;
+    long items = 0, finish = 0;
     for (int i = 0; i < here; ++i) {
       const int k = first + i;
       if (rows[k] <= 0 || n_cols[k] <= 0 || rows[k] >= (1L << 31) || n_cols[k] >= (1L << 31) || !g[k] || !out[k])
@@ -499,35 +497,34 @@ int seld_multi_column_sums(const void* const* g, void* const* out, const int64_t
         return fail(kErrUnsupported, "seld_multi_column_sums: the column count must be a multiple of 8 and the matrix 16-byte aligned");
       const long rb = multi_column_row_blocks(rows[k], n_cols[k]);
       const long col_blocks = (n_cols[k] + 255) / 256;
-      if (used_floats + rb * n_cols[k] > partial_floats || used_counters + col_blocks > n_counters)
+      if (used_floats + rb * n_cols[k] > partial_floats)
         return fail(kErrInvalidArgument, "seld_multi_column_sums: scratch too small (seld_multi_column_sums_scratch)");
-      b.d[i] = ColDesc{g[k], out[k], partial + used_floats, counters + used_counters, static_cast<int>(rows[k]),
-                       static_cast<int>(n_cols[k]), static_cast<int>(rb), static_cast<int>((rows[k] + rb - 1) / rb), items,
-                       flags[k] & 3};
+      b.d[i] = ColDesc{g[k], out[k], partial + used_floats, static_cast<int>(rows[k]), static_cast<int>(n_cols[k]),
+                       static_cast<int>(rb), static_cast<int>((rows[k] + rb - 1) / rb), static_cast<int>(items),
+                       static_cast<int>(finish), flags[k] & 3, 0};
       used_floats += rb * n_cols[k];
-      used_counters += col_blocks;
-      items += static_cast<int>(col_blocks * rb);
+      items += col_blocks * rb;
+      finish += (n_cols[k] + 15) / 16;
+      if (items >= (1L << 31) || finish >= (1L << 31)) return fail(kErrUnsupported, "seld_multi_column_sums: too much work for one launch");
     }
     b.n = here;
-    hipLaunchKernelGGL(multi_column_sums_kernel, dim3(static_cast<unsigned>(items)), dim3(kGlueThreads), 0, stream, b);
+    hipLaunchKernelGGL(multi_column_partials_kernel, dim3(static_cast<unsigned>(items)), dim3(kGlueThreads), 0, stream, b);
+    hipLaunchKernelGGL(multi_column_finish_kernel, dim3(static_cast<unsigned>(finish)), dim3(kGlueThreads), 0, stream, b);
   }
   SELD_HIP_TRY(hipGetLastError());
   return kOk;
 }
 
-int seld_multi_column_sums_scratch(const int64_t* rows, const int64_t* n_cols, int count, int64_t* partial_floats,
-                                   int64_t* n_counters) {
+int seld_multi_column_sums_scratch(const int64_t* rows, const int64_t* n_cols, int count, int64_t* partial_floats) {
   using namespace seld;
-  if (count < 0 || (count > 0 && (!rows || !n_cols)) || !partial_floats || !n_counters)
+  if (count < 0 || (count > 0 && (!rows || !n_cols)) || !partial_floats)
     return fail(kErrInvalidArgument, "seld_multi_column_sums_scratch: bad argument");
-  long f = 0, c = 0;
+  long f = 0;
   for (int k = 0; k < count; ++k) {
     if (rows[k] <= 0 || n_cols[k] <= 0) return fail(kErrInvalidArgument, "seld_multi_column_sums_scratch: bad extent");
     f += multi_column_row_blocks(rows[k], n_cols[k]) * n_cols[k];
-    c += (n_cols[k] + 255) / 256;
   }
   *partial_floats = f;
-  *n_counters = c;
   return kOk;
 }
 

@@ -81,8 +81,8 @@ def _declare(lib):
     lib.seld_column_sums.argtypes = [_ptr, _int, _i64, _i64, _ptr, _ptr, _int, _ptr]
     _pp, _pi64, _pi32 = ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32)
     lib.seld_multi_sum_chunks.argtypes = [_pp, _pp, _pi64, _pi32, _pi32, _int, _ptr]
-    lib.seld_multi_column_sums_scratch.argtypes = [_pi64, _pi64, _int, _pi64, _pi64]
-    lib.seld_multi_column_sums.argtypes = [_pp, _pp, _pi64, _pi64, _pi32, _int, _ptr, _i64, _ptr, _i64, _ptr]
+    lib.seld_multi_column_sums_scratch.argtypes = [_pi64, _pi64, _int, _pi64]
+    lib.seld_multi_column_sums.argtypes = [_pp, _pp, _pi64, _pi64, _pi32, _int, _ptr, _i64, _ptr]
     lib.seld_column_sums_blocks.argtypes = [_i64, _i64]
     lib.seld_column_sums_blocks.restype = ctypes.c_int64
     lib.seld_conv_weight_flip_transpose.argtypes = [_ptr, _int, _i64, _i64, _ptr, _ptr]
@@ -864,12 +864,13 @@ def multi_sum_chunks(pairs) -> None:
               "seld_multi_sum_chunks")
 
 
-_column_scratch = {}      # device index -> (partial fp32, counters uint32 as int32 storage): grown on demand, counters zero
+_column_scratch = {}      # device index -> fp32 scratch for the row-block partials, grown on demand
+_retired_scratch = []
 
 
 def multi_column_sums(pairs) -> None:
-    """``out[n] = sum_r g[r, n]`` for every (g [rows, N], out [N]) pair in ONE launch per 40 pairs (csrc/glue.hip
-    multi_column_sums_kernel: the last workgroup of a column block adds the row blocks in index order)."""
+    """``out[n] = sum_r g[r, n]`` for every (g [rows, N], out [N]) pair in TWO launches per 40 pairs (csrc/glue.hip
+    multi_column_partials_kernel / multi_column_finish_kernel: row blocks in parallel, added in a fixed order)."""
     pairs = list(pairs)
     if not pairs:
         return
@@ -883,21 +884,21 @@ def multi_column_sums(pairs) -> None:
     rows = (ctypes.c_int64 * n)(*[g.shape[0] for g, _ in pairs])
     cols = (ctypes.c_int64 * n)(*[g.shape[1] for g, _ in pairs])
     flags = (ctypes.c_int32 * n)(*[_is_bf16(g) | (_is_bf16(o) << 1) for g, o in pairs])
-    need_f, need_c = ctypes.c_int64(0), ctypes.c_int64(0)
-    check(lib.seld_multi_column_sums_scratch(rows, cols, n, ctypes.byref(need_f), ctypes.byref(need_c)),
-          "seld_multi_column_sums_scratch")
+    need_f = ctypes.c_int64(0)
+    check(lib.seld_multi_column_sums_scratch(rows, cols, n, ctypes.byref(need_f)), "seld_multi_column_sums_scratch")
     device = pairs[0][0].device
     index = ensure_init(device)
     scratch = _column_scratch.get(index)
-    if scratch is None or scratch[0].numel() < need_f.value or scratch[1].numel() < need_c.value:
+    if scratch is None or scratch.numel() < need_f.value:
         if torch.cuda.is_current_stream_capturing():
             raise SeldNativeError("multi_column_sums: the scratch must be sized by an eager call before a graph capture")
-        scratch = (torch.empty(max(need_f.value, 1 << 20), dtype=torch.float32, device=device),
-                   torch.zeros(max(need_c.value, 4096), dtype=torch.int32, device=device))
+        if scratch is not None:
+            _retired_scratch.append(scratch)          # a captured graph may still hold its address: never handed back
+        scratch = torch.empty(max(need_f.value, 1 << 20), dtype=torch.float32, device=device)
         _column_scratch[index] = scratch
     with _device_guard(index):
-        check(lib.seld_multi_column_sums(src, dst, rows, cols, flags, n, _p(scratch[0]), scratch[0].numel(), _p(scratch[1]),
-                                         scratch[1].numel(), _stream_ptr(device)), "seld_multi_column_sums")
+        check(lib.seld_multi_column_sums(src, dst, rows, cols, flags, n, _p(scratch), scratch.numel(), _stream_ptr(device)),
+              "seld_multi_column_sums")
 
 
 def gru_dwhh_finish(p_gi: torch.Tensor, p_n: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
