@@ -73,6 +73,18 @@ int seld_logmel_spectrum_f32(const float* pcm, int64_t N, int64_t C, int64_t L, 
 int seld_logmel_spectrum_i16(const int16_t* pcm, int64_t N, int64_t C, int64_t L, float* out, int64_t sN, int64_t sC,
                              int64_t sM, int64_t sT, float* spec_complex, void* stream);
 
+/* The strided log-mel pass that also writes every bin's PHASOR X / |X| as a pair of signed 16-bit fixed-point numbers
+ * (word = (re & 0xffff) | im << 16, scale 32767; 0 for a silent bin, |X|^2 <= 1e-12): phasors_q15
+ * [N][C][F][seld_phasor_pitch()] words, bins 0..480 of a row written.  This is what GCC-PHAT consumes (seld_gcc_phat_q15):
+ * 4 B per bin instead of the 8 B of the complex64 spectrum -- half the HBM bytes between the two kernels -- with the
+ * phase transform's reciprocal square root taken once per (channel, bin) where |X|^2 is formed anyway (extends
+ * dataset.py:27-58; no upstream counterpart). */
+int64_t seld_phasor_pitch(void);
+int seld_logmel_phasors_f32(const float* pcm, int64_t N, int64_t C, int64_t L, float* out, int64_t sN, int64_t sC,
+                            int64_t sM, int64_t sT, uint32_t* phasors_q15, void* stream);
+int seld_logmel_phasors_i16(const int16_t* pcm, int64_t N, int64_t C, int64_t L, float* out, int64_t sN, int64_t sC,
+                            int64_t sM, int64_t sT, uint32_t* phasors_q15, void* stream);
+
 /* ---- north-star additions without a reference implementation --------------
  * The reference computes its STFT only implicitly inside torchaudio and has no intensity-vector / GCC-PHAT
  * features; these entry points follow the DCASE SELD-baseline definitions.
@@ -95,6 +107,11 @@ int seld_foa_intensity(const float* spec_complex, int64_t N, int64_t F, float* o
  *   any other layout takes the fp32 FFT kernel. */
 int seld_gcc_phat(const float* spec_complex, int64_t N, int64_t C, int64_t F, float* out, int64_t sN, int64_t sC,
                   int64_t sM, int64_t sT, void* stream);
+
+/* The same lags from the Q15 phasors of seld_logmel_phasors_* (matrix-core kernel only: unit lag stride, 16-byte aligned
+ * rows).  out as for seld_gcc_phat. */
+int seld_gcc_phat_q15(const uint32_t* phasors_q15, int64_t N, int64_t C, int64_t F, float* out, int64_t sN, int64_t sC,
+                      int64_t sM, int64_t sT, void* stream);
 
 /* Host copy of the matrix-core kernel's constant operand -- no GPU needed (used by the CPU tests): 2 x 3 x 16 fragments of
  * 64 lanes x 8 IEEE binary16 values = 49 152 halves; fragment (part, tile, kstep), lane l, element j holds, for bin

@@ -19,7 +19,8 @@ struct LogmelArgs {
   long chunk;           // consecutive interior iterations per wavefront (main kernel)
   long sN, sC, sM, sT;  // output strides (elements): clip, channel, mel band, frame
   LogmelTables tab;
-  float* spec;          // kSpec instantiations: the un-packed spectra as well, [rows][F][481] complex64 (else unused)
+  float* spec;          // kSpec 1: the un-packed spectra as well, [rows][F][481] complex64; kSpec 2: the Q15 phasors,
+                        // [rows][F][kPhasorPitch] words (logmel_core.h phase_c_store_phasors); else unused
   long main_blocks;     // main kernel: workgroups [0, main_blocks) run interior pipelines, the rest edge iterations
 };
 
@@ -46,7 +47,7 @@ __device__ __forceinline__ float lane_below(float v) {
 
 // One edge iteration (index e of rows * edge_per_row) by one wavefront: generic load path (reflection, frames past the end
 // masked), no pipelining.
-template <typename T, bool kSpec>
+template <typename T, int kSpec>
 __device__ __forceinline__ void edge_iteration(const LogmelArgs& a, long e, int lane, const float* tab, float* lds, int seg,
                                                float* const (&pp)[16], const LaneConsts& consts) {
   const int h = lane >> 5;
@@ -67,12 +68,19 @@ __device__ __forceinline__ void edge_iteration(const LogmelArgs& a, long e, int 
   SELD_WAVE_SYNC();
   cf m[16];
   phase_c_load(lane, lds, m);
-  if (kSpec) {
+  if (kSpec == 1) {
     const long fa = tf + 2 * h;
     float* base = a.spec + (row * a.F + fa) * (2 * kBins);
     phase_c_spectrum(lane, z, m, fa < a.F ? base : nullptr, fa + 1 < a.F ? base + 2 * kBins : nullptr);
   }
-  phase_c_store(lane, pp, z, m);
+  if (kSpec == 2) {
+    const long fa = tf + 2 * h;
+    unsigned* base = reinterpret_cast<unsigned*>(a.spec) + (row * a.F + tf) * kPhasorPitch;
+    phase_c_store_phasors(lane, pp, z, m, base, static_cast<unsigned>(2 * h * kPhasorPitch + (lane & 31)), fa < a.F,
+                          fa + 1 < a.F);
+  } else {
+    phase_c_store(lane, pp, z, m);
+  }
   SELD_WAVE_SYNC();
   LaneAcc acc;
   phase_d_accumulate(lane, lds, tab, seg, acc);
@@ -95,7 +103,7 @@ __device__ __forceinline__ void edge_iteration(const LogmelArgs& a, long e, int 
 // covered by the un-packing / mel / store phases and by the SIMD's other wavefront.
 // kSpec: the spectra the power rows are formed from are also written out (frame-major rows of 481 complex) -- the spatial
 // features (csrc/spatial.hip) read them, and a second pass over the PCM through stft_kernel is not needed.
-template <typename T, bool kSpec>
+template <typename T, int kSpec>
 __global__ __launch_bounds__(kMainWaves * 64, 2) void logmel_main_kernel(LogmelArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
@@ -161,14 +169,23 @@ __global__ __launch_bounds__(kMainWaves * 64, 2) void logmel_main_kernel(LogmelA
     SELD_WAVE_SYNC();
     phase_b_store(lane, lds, z);
     SELD_WAVE_SYNC();
-    load_samples<T, true>(lane, pcm + nrow * a.L, a.L, nitr * kFramesPerIter + 2 * h, s);   // prefetch
+    // the next iteration's samples: requested here, a whole un-pack + mel + store phase ahead -- except in the fp32
+    // phasor instantiation, whose un-packing needs the 48 registers (requested after it: no scratch, 64 B per lane before)
+    constexpr bool kLatePrefetch = kSpec == 2 && sizeof(T) == 4;
+    if (!kLatePrefetch) load_samples<T, true>(lane, pcm + nrow * a.L, a.L, nitr * kFramesPerIter + 2 * h, s);
     cf m[16];
     phase_c_load(lane, lds, m);
-    if (kSpec) {                                             // interior iterations: all four frames exist
+    if (kSpec == 1) {                                        // interior iterations: all four frames exist
       float* base = a.spec + ((row * a.F + itr * kFramesPerIter) * kBins) * 2 + h * (2 * 2 * kBins);
       phase_c_spectrum(lane, z, m, base, base + 2 * kBins);
     }
-    phase_c_store(lane, pp, z, m);
+    if (kSpec == 2) {
+      unsigned* base = reinterpret_cast<unsigned*>(a.spec) + (row * a.F + itr * kFramesPerIter) * kPhasorPitch;   // scalar
+      phase_c_store_phasors(lane, pp, z, m, base, static_cast<unsigned>(2 * h * kPhasorPitch + (lane & 31)), true, true);
+    } else {
+      phase_c_store(lane, pp, z, m);
+    }
+    if (kLatePrefetch) load_samples<T, true>(lane, pcm + nrow * a.L, a.L, nitr * kFramesPerIter + 2 * h, s);
     SELD_WAVE_SYNC();
     LaneAcc acc;
     phase_d_accumulate(lane, lds, tab, seg, acc);
@@ -189,7 +206,7 @@ __global__ __launch_bounds__(kMainWaves * 64, 2) void logmel_main_kernel(LogmelA
 // ---- Edge kernel: the first iteration of every row (reflection on the left) and the last one or two
 // (reflection on the right, frames past the end masked).  One wavefront per edge iteration, no pipelining:
 // rows * edge_per_row iterations in total (256 for 32 one-minute clips) against ~96 000 interior ones.
-template <typename T, bool kSpec>
+template <typename T, int kSpec>
 __global__ __launch_bounds__(kEdgeWaves * 64, 1) void logmel_edge_kernel(LogmelArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
@@ -300,7 +317,7 @@ static int launch_stft(const T* pcm, int64_t N, int64_t C, int64_t L, float* out
   return kOk;
 }
 
-template <typename T, bool kSpec = false>
+template <typename T, int kSpec = 0>
 static int launch_logmel(const T* pcm, int64_t N, int64_t C, int64_t L, float* out, int layout,
                          hipStream_t stream, const int64_t* strides = nullptr, float* spec = nullptr) {
   DeviceState* st = current_state();
@@ -345,8 +362,9 @@ static int launch_logmel(const T* pcm, int64_t N, int64_t C, int64_t L, float* o
   a.chunk = 1;
   a.spec = spec;
 
-  const unsigned bit = kSpec ? (sizeof(T) == 4 ? kAttrLogmelSpecF32 : kAttrLogmelSpecI16)
-                             : (sizeof(T) == 4 ? kAttrLogmelF32 : kAttrLogmelI16);
+  const unsigned bit = kSpec == 2 ? (sizeof(T) == 4 ? kAttrLogmelPhasorF32 : kAttrLogmelPhasorI16)
+                       : kSpec == 1 ? (sizeof(T) == 4 ? kAttrLogmelSpecF32 : kAttrLogmelSpecI16)
+                                    : (sizeof(T) == 4 ? kAttrLogmelF32 : kAttrLogmelI16);
   if (need_lds(st, bit)) {                 // once per device (seld_common.h)
     SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_main_kernel<T, kSpec>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, kMainLdsBytes));
@@ -410,14 +428,30 @@ int seld_logmel_i16_strided(const int16_t* pcm, int64_t N, int64_t C, int64_t L,
 int seld_logmel_spectrum_f32(const float* pcm, int64_t N, int64_t C, int64_t L, float* out, int64_t sN, int64_t sC,
                              int64_t sM, int64_t sT, float* spec_complex, void* stream) {
   const int64_t strides[4] = {sN, sC, sM, sT};
-  return seld::launch_logmel<float, true>(pcm, N, C, L, out, 0, static_cast<hipStream_t>(stream), strides, spec_complex);
+  return seld::launch_logmel<float, 1>(pcm, N, C, L, out, 0, static_cast<hipStream_t>(stream), strides, spec_complex);
 }
 
 int seld_logmel_spectrum_i16(const int16_t* pcm, int64_t N, int64_t C, int64_t L, float* out, int64_t sN, int64_t sC,
                              int64_t sM, int64_t sT, float* spec_complex, void* stream) {
   const int64_t strides[4] = {sN, sC, sM, sT};
-  return seld::launch_logmel<int16_t, true>(pcm, N, C, L, out, 0, static_cast<hipStream_t>(stream), strides, spec_complex);
+  return seld::launch_logmel<int16_t, 1>(pcm, N, C, L, out, 0, static_cast<hipStream_t>(stream), strides, spec_complex);
 }
+
+int seld_logmel_phasors_f32(const float* pcm, int64_t N, int64_t C, int64_t L, float* out, int64_t sN, int64_t sC,
+                            int64_t sM, int64_t sT, uint32_t* phasors_q15, void* stream) {
+  const int64_t strides[4] = {sN, sC, sM, sT};
+  return seld::launch_logmel<float, 2>(pcm, N, C, L, out, 0, static_cast<hipStream_t>(stream), strides,
+                                       reinterpret_cast<float*>(phasors_q15));
+}
+
+int seld_logmel_phasors_i16(const int16_t* pcm, int64_t N, int64_t C, int64_t L, float* out, int64_t sN, int64_t sC,
+                            int64_t sM, int64_t sT, uint32_t* phasors_q15, void* stream) {
+  const int64_t strides[4] = {sN, sC, sM, sT};
+  return seld::launch_logmel<int16_t, 2>(pcm, N, C, L, out, 0, static_cast<hipStream_t>(stream), strides,
+                                         reinterpret_cast<float*>(phasors_q15));
+}
+
+int64_t seld_phasor_pitch(void) { return seld::kPhasorPitch; }
 
 int seld_stft_f32(const float* pcm, int64_t N, int64_t C, int64_t L, float* out_complex, void* stream) {
   return seld::launch_stft<float>(pcm, N, C, L, out_complex, static_cast<hipStream_t>(stream));

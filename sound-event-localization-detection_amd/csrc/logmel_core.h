@@ -261,6 +261,46 @@ SELD_HD void phase_c_store(int lane, float* const (&pp)[16], const cf (&z)[kN2],
   }
 }
 
+// Variant of phase C for the GCC-PHAT feature set: besides the power rows, every bin's PHASOR X / |X| goes to global memory
+// as a pair of signed 16-bit fixed-point numbers (re | im << 16, scale 32767: |component| <= 1, step 3.05e-5 -- sixteen
+// times finer than fp16 near 1) -- 4 B per bin instead of the 8 B of the complex64 spectrum, and the phase transform's
+// reciprocal square root is taken here, once per (channel, bin), from the |X|^2 that is being formed anyway.  A silent bin
+// (|X|^2 <= kSilencePower) is stored as 0 (csrc/spatial.hip turns its products into 1).  Rows of kPhasorPitch words.
+constexpr float kSilencePower = 1e-12f;
+constexpr int kPhasorPitch = 488;            // 481 bins + 7: rows stay 16-byte aligned (bins 481..487 are never written)
+
+SELD_HD unsigned phasor_q15(float re, float im, float power) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float rs = __frsqrt_rn(power);                 // v_rsq_f32: 1 ulp, far below the 3e-5 quantisation step
+#else
+  const float rs = 1.0f / sqrtf(power);
+#endif
+  const float inv = power > kSilencePower ? 32767.0f * rs : 0.0f;
+  const int qr = static_cast<int>(rintf(re * inv)), qi = static_cast<int>(rintf(im * inv));
+  return (static_cast<unsigned>(qr) & 0xffffu) | (static_cast<unsigned>(qi) << 16);
+}
+
+// ``base`` is wavefront-uniform (a scalar register pair), ``off_a`` this lane's 32-bit word offset of bin l of frame a
+// (frame b one row further): every store is scalar base + one offset register + an immediate.
+SELD_HD void phase_c_store_phasors(int lane, float* const (&pp)[16], const cf (&z)[kN2], const cf (&m)[16],
+                                   unsigned* base, unsigned off_a, bool have_a, bool have_b) {
+  const int l = lane & 31;
+  unsigned* pa = have_a ? base + off_a : nullptr;                      // bin l + 32 r is at +32 r
+  unsigned* pb = have_b ? base + off_a + kPhasorPitch : nullptr;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (r < 15 || l == 0) {
+      const cf u = cf_fma(cf_make(m[r].x, m[r].x), cf_make(1.0f, -1.0f), cf_make(z[r].x, z[r].x));   // (zr + mr, zr - mr)
+      const cf v = cf_fma(cf_make(m[r].y, m[r].y), cf_make(-1.0f, 1.0f), cf_make(z[r].y, z[r].y));   // (zi - mi, zi + mi)
+      const cf p = cf_fma(v, v, cf_mul(u, u));
+      pp[r][0] = p.x;
+      pp[r][kPPitch] = p.y;
+      if (pa) pa[32 * r] = phasor_q15(u.x, v.x, p.x);                  // Xa = (zr + mr, zi - mi)
+      if (pb) pb[32 * r] = phasor_q15(v.y, -u.y, p.y);                 // Xb = (zi + mi, mr - zr)
+    }
+  }
+}
+
 // Variant of phase C for the STFT export: the un-packed complex spectra of the two frames go straight to
 // global memory (frame-major rows of 481 complex: 32 lanes x 8 B = one 256-B run per store).
 //   Xa = (zr + mr, zi - mi) ,  Xb = (zi + mi, mr - zr)   (the 1/2 is in the window table)

@@ -61,6 +61,9 @@ enum LdsAttrBit : unsigned {
   kAttrLogmelSpecF32 = 1u << 7,
   kAttrLogmelSpecI16 = 1u << 8,
   kAttrGccMfma = 1u << 9,
+  kAttrLogmelPhasorF32 = 1u << 10,
+  kAttrLogmelPhasorI16 = 1u << 11,
+  kAttrGccMfmaQ15 = 1u << 12,
 };
 
 // true when `bit` still has to be set up on this device (the caller then sets its attributes and calls lds_attr_set)

@@ -20,6 +20,8 @@
 
 #include <vector>
 
+#include <type_traits>
+
 #include "seld_common.h"
 
 extern "C" int seld_gcc_table_host(uint16_t* table);      // include/seld_hip.h (defined below)
@@ -159,7 +161,7 @@ __device__ __forceinline__ void pair_channels(int p, int C, int& m, int& n) {
 constexpr int kGccThreads = kGccWaves * 64;
 // |X|^2 at or below this is a SILENT bin (phase factor 1): below any recording's noise floor, above the ~1e-7 of its
 // neighbour's amplitude that the packed two-frame transform leaves in a frame of digital silence (oracle/features.py)
-constexpr float kGccSilencePower = 1e-12f;
+constexpr float kGccSilencePower = kSilencePower;      // logmel_core.h (the Q15 phasors apply the same rule at the source)
 constexpr int kGccPre = (8 * kBins + kGccThreads - 1) / kGccThreads;          // complex elements per lane and frame: 9
 
 // conj(a) * b as two packed operations
@@ -336,7 +338,7 @@ constexpr int kGmTableBytes = kGmTableFrags * 64 * 16;            // 98 304 B
 constexpr int kGmLdsBytes = kGmTableBytes + 2 * kGmUFloats * 4 + 16;   // 160 784 B (+ the two silent-bin flags)
 
 struct GccMfmaArgs {
-  const float* spec;     // [N][C][F][481] complex64
+  const float* spec;     // [N][C][F][481] complex64; the kQ15 instantiation: [N][C][F][kPhasorPitch] Q15 phasors (re | im << 16)
   float* out;            // out[n*sN + pair*sC + j*sM + t*sT], j = 0..63 (lag j - 32)
   long N, C, F;
   long sN, sC, sM, sT;
@@ -494,6 +496,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 constexpr int kGmBinsPerLane = 4;                                  // bins tt, tt + 128, tt + 256, tt + 384 (< 481) of every channel
 
+// kQ15: the input is the log-mel pass's Q15 phasors (logmel_core.h phase_c_store_phasors: X / |X| already taken, 4 B per
+// bin -- half the HBM bytes of the complex64 spectra on both sides, and no reciprocal square root here); otherwise raw
+// complex64 spectra (seld_gcc_phat on an STFT).
+template <bool kQ15>
 __global__ __launch_bounds__(kGmThreads, 1) void gcc_mfma_kernel(GccMfmaArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
@@ -513,12 +519,14 @@ __global__ __launch_bounds__(kGmThreads, 1) void gcc_mfma_kernel(GccMfmaArgs a) 
   const int n_tiles = (n_pairs + 15) / 16;
   const int n_ch = static_cast<int>(a.C);
   const long total = a.N * a.F;
-  const int ch_stride_i = static_cast<int>(a.F * kBins);
+  constexpr int kRow = kQ15 ? kPhasorPitch : kBins;                // elements (words / complex values) per (channel, frame) row
+  typedef typename std::conditional<kQ15, unsigned, float2>::type In;
+  const int ch_stride_i = static_cast<int>(a.F * kRow);
   const int tt = tid & 127;                                        // index within the slot's two wavefronts
-  const float2* spec2 = reinterpret_cast<const float2*>(a.spec);
+  const In* spec2 = reinterpret_cast<const In*>(a.spec);
   auto frame_base = [&](long f) {
     const long n = f / a.F;
-    return spec2 + (n * a.C * a.F + (f - n * a.F)) * kBins;
+    return spec2 + (n * a.C * a.F + (f - n * a.F)) * kRow;
   };
   // Lane tt stages bins tt + 128 i (i = 0..3; the last only for tt < 97) of every channel.  Where a bin goes in its chunk
   // (gm_chunk_slot) is loop invariant: channel c adds 16 floats -- an immediate -- and channels 4..7 rotate one float4
@@ -536,7 +544,7 @@ __global__ __launch_bounds__(kGmThreads, 1) void gcc_mfma_kernel(GccMfmaArgs a) 
     src_bin[i] = static_cast<unsigned>(bin);
   }
   const bool last_bin_valid = tt + 128 * (kGmBinsPerLane - 1) < kBins;
-  auto request = [&](const float2* src, float2 (&pre)[8][kGmBinsPerLane]) {
+  auto request = [&](const In* src, In (&pre)[8][kGmBinsPerLane]) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const unsigned coff = static_cast<unsigned>(c < n_ch ? c : 0) * static_cast<unsigned>(ch_stride_i);   // uniform
@@ -548,14 +556,14 @@ __global__ __launch_bounds__(kGmThreads, 1) void gcc_mfma_kernel(GccMfmaArgs a) 
   long f = 2L * blockIdx.x + slot;                                 // this slot's frame
   // (A second register set of requests, issued two iterations ahead, was tried: no gain -- the loop is not waiting for HBM
   // -- and its 64 registers pushed the products' LDS reads back to their use.)
-  float2 pre_a[8][kGmBinsPerLane];
+  In pre_a[8][kGmBinsPerLane];
   auto clamp_frame = [&](long fr) { return fr < total ? fr : (f < total ? f : total - 1); };
   request(frame_base(clamp_frame(f)), pre_a);
   int* flags = reinterpret_cast<int*>(smem_raw + kGmTableBytes + 2 * kGmUFloats * 4);   // silent-bin flag per iteration parity
   if (tid < 2) flags[tid] = 0;
   __syncthreads();                                                 // the table and the zeroed buffers are in place
   int parity = 0;
-  auto iteration = [&](float2 (&pre)[8][kGmBinsPerLane]) {
+  auto iteration = [&](In (&pre)[8][kGmBinsPerLane]) {
     lds_barrier();                                                 // the previous frames' readers are done
     if (tid == 0) flags[parity ^ 1] = 0;                           // (read last in the previous iteration)
     int zero = 0;
@@ -565,13 +573,20 @@ __global__ __launch_bounds__(kGmThreads, 1) void gcc_mfma_kernel(GccMfmaArgs a) 
         float nx[kGmBinsPerLane], ny[kGmBinsPerLane];
 #pragma unroll
         for (int i = 0; i < kGmBinsPerLane; ++i) {
-          const float2 x = pre[c][i];
-          const float mag2 = x.x * x.x + x.y * x.y;
-          const bool sounding = mag2 > kGccSilencePower;
-          const float inv = sounding ? rsqrtf(mag2) : 0.0f;
-          zero |= sounding ? 0 : 1;                                // (a repeated last bin flags what its owner flags)
-          nx[i] = x.x * inv;
-          ny[i] = x.y * inv;
+          if constexpr (kQ15) {
+            const unsigned w = pre[c][i];                          // a silent bin was stored as 0 by the log-mel pass
+            zero |= w == 0u ? 1 : 0;                               // (a repeated last bin flags what its owner flags)
+            nx[i] = static_cast<float>(static_cast<int>(w << 16) >> 16) * (1.0f / 32767.0f);
+            ny[i] = static_cast<float>(static_cast<int>(w) >> 16) * (1.0f / 32767.0f);
+          } else {
+            const float2 x = pre[c][i];
+            const float mag2 = x.x * x.x + x.y * x.y;
+            const bool sounding = mag2 > kGccSilencePower;
+            const float inv = sounding ? rsqrtf(mag2) : 0.0f;
+            zero |= sounding ? 0 : 1;
+            nx[i] = x.x * inv;
+            ny[i] = x.y * inv;
+          }
         }
         float* uc = u + 16 * (c & 3) + 64 * (c >> 2);              // channel c: + 16 c floats
 #pragma unroll
@@ -666,6 +681,38 @@ int seld_gcc_table_host(uint16_t* table) {
   return kOk;
 }
 
+static int launch_gcc_q15(seld::DeviceState* st, const uint32_t* phasors, int64_t N, int64_t C, int64_t F, float* out,
+                          int64_t sN, int64_t sC, int64_t sM, int64_t sT, void* stream_) {
+  using namespace seld;
+  GccMfmaArgs a{reinterpret_cast<const float*>(phasors), out, N, C, F, sN, sC, sM, sT, st->gcc_table};
+  long blocks = (N * F + 1) / 2;
+  if (blocks > st->num_cus) blocks = st->num_cus;           // persistent: the 96 KB table is staged once per workgroup
+  if (need_lds(st, kAttrGccMfmaQ15)) {
+    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gcc_mfma_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kGmLdsBytes));
+    lds_attr_set(st, kAttrGccMfmaQ15);
+  }
+  hipLaunchKernelGGL(gcc_mfma_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(kGmThreads), kGmLdsBytes,
+                     static_cast<hipStream_t>(stream_), a);
+  SELD_HIP_TRY(hipGetLastError());
+  return kOk;
+}
+
+int seld_gcc_phat_q15(const uint32_t* phasors, int64_t N, int64_t C, int64_t F, float* out, int64_t sN, int64_t sC,
+                      int64_t sM, int64_t sT, void* stream_) {
+  using namespace seld;
+  DeviceState* st = current_state();
+  if (!st) return kErrNotInitialised;
+  if (!phasors || !out) return fail(kErrInvalidArgument, "seld_gcc_phat_q15: null pointer");
+  if (N <= 0 || F <= 0) return fail(kErrInvalidArgument, "seld_gcc_phat_q15: N and F must be positive");
+  if (C < 2 || C > 8) return fail(kErrUnsupported, "seld_gcc_phat_q15: 2..8 channels");
+  if (C * F * kPhasorPitch >= (1L << 31)) return fail(kErrUnsupported, "seld_gcc_phat_q15: a clip's phasors exceed 2^31 words");
+  // the kernel stores four consecutive lags as one vector: unit lag stride, 16-byte aligned rows
+  const bool vector_rows = sM == 1 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && sN % 4 == 0 && sC % 4 == 0 && sT % 4 == 0;
+  if (!vector_rows) return fail(kErrUnsupported, "seld_gcc_phat_q15: needs unit lag stride and 16-byte aligned rows");
+  return launch_gcc_q15(st, phasors, N, C, F, out, sN, sC, sM, sT, stream_);
+}
+
 int seld_gcc_phat(const float* spec_complex, int64_t N, int64_t C, int64_t F, float* out, int64_t sN, int64_t sC,
                   int64_t sM, int64_t sT, void* stream_) {
   using namespace seld;
@@ -685,11 +732,11 @@ int seld_gcc_phat(const float* spec_complex, int64_t N, int64_t C, int64_t F, fl
     long blocks = (N * F + 1) / 2;
     if (blocks > st->num_cus) blocks = st->num_cus;         // persistent: the 96 KB table is staged once per workgroup
     if (need_lds(st, kAttrGccMfma)) {
-      SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gcc_mfma_kernel),
+      SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gcc_mfma_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kGmLdsBytes));
       lds_attr_set(st, kAttrGccMfma);
     }
-    hipLaunchKernelGGL(gcc_mfma_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kGmThreads), kGmLdsBytes,
+    hipLaunchKernelGGL(gcc_mfma_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(kGmThreads), kGmLdsBytes,
                        static_cast<hipStream_t>(stream_), a);
     SELD_HIP_TRY(hipGetLastError());
     return kOk;

@@ -57,6 +57,10 @@ def _declare(lib):
     for fn in (lib.seld_logmel_spectrum_f32, lib.seld_logmel_spectrum_i16):
         fn.argtypes = [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr]
         fn.restype = ctypes.c_int
+    for fn in (lib.seld_logmel_phasors_f32, lib.seld_logmel_phasors_i16):
+        fn.argtypes = [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr]
+    lib.seld_phasor_pitch.restype = ctypes.c_int64
+    lib.seld_gcc_phat_q15.argtypes = [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr]
     lib.seld_gcc_table_host.argtypes = [_ptr]
     lib.seld_gcc_phat.argtypes = [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr]
     lib.seld_labels_rasterise.argtypes = [_ptr, _i64, _i64, _int, _int, _ptr, _ptr]
@@ -981,6 +985,19 @@ def spatial_features(pcm: torch.Tensor, kind: str) -> torch.Tensor:
     s_n, s_t, s_c, s_m = frames * total * N_MELS, total * N_MELS, N_MELS, 1
     lib = load_library()
     stream = _stream_ptr(pcm.device)
+    import os
+    mode = os.environ.get("SELD_GCC", "mfma")                # developer A/B: "fft" = the FFT kernel, "spectra" = the
+    if kind == "logmel_gcc" and mode not in ("fft", "spectra"):     # matrix-core kernel fed with complex64 spectra
+        # default: the log-mel pass also writes every bin's phasor X / |X| as Q15 pairs (4 B per bin instead of the 8 B of
+        # the complex64 spectrum: half the HBM bytes on both sides) and the matrix-core GCC-PHAT kernel reads those
+        pitch = int(lib.seld_phasor_pitch())
+        with _device_guard(index):
+            phasors = torch.empty((n, c, frames, pitch), dtype=torch.int32, device=pcm.device)
+            fn = lib.seld_logmel_phasors_f32 if pcm.dtype == torch.float32 else lib.seld_logmel_phasors_i16
+            check(fn(_p(pcm), n, c, length, _p(out), s_n, s_c, s_m, s_t, _p(phasors), stream), "seld_logmel_phasors")
+            tail = ctypes.c_void_p(out.data_ptr() + c * N_MELS * 4)          # channel offset c
+            check(lib.seld_gcc_phat_q15(_p(phasors), n, c, frames, tail, s_n, s_c, s_m, s_t, stream), "seld_gcc_phat_q15")
+        return out[0] if squeeze else out
     with _device_guard(index):
         # one pass over the PCM: the log-mel channels and the spectra the spatial kernels read
         spec = torch.empty((n, c, frames, N_FFT // 2 + 1, 2), dtype=torch.float32, device=pcm.device)

@@ -41,11 +41,12 @@ def test_foa_intensity_vectors(gpu_device):
     assert np.abs(ref[0]).max() > 0.1                                     # the planted correlation shows up
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "fft"])
+@pytest.mark.parametrize("kernel", ["mfma", "spectra", "fft"])
 @pytest.mark.parametrize("channels", [8, 4, 2])
 def test_gcc_phat(gpu_device, channels, kernel, monkeypatch):
-    """Both GCC-PHAT kernels (csrc/spatial.hip): the matrix-core one (default) and the FFT-based one that serves outputs
-    whose lag stride is not 1 (SELD_GCC=fft selects it for any layout)."""
+    """The GCC-PHAT paths (csrc/spatial.hip): the matrix-core kernel fed with the log-mel pass's Q15 phasors (default), the
+    same kernel fed with complex64 spectra (SELD_GCC=spectra: what seld_gcc_phat does on an exported STFT), and the
+    FFT-based one that serves outputs whose lag stride is not 1 (SELD_GCC=fft)."""
     import seld_native
     monkeypatch.setenv("SELD_GCC", kernel)
     pcm = ofeat.synth_pcm(6, channels, 12000 + 17, "noise")
@@ -73,7 +74,7 @@ def test_batched_spatial_features(gpu_device):
         assert torch.equal(gcc[i], seld_native.spatial_features(pcm[i], "logmel_gcc"))
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "fft"])
+@pytest.mark.parametrize("kernel", ["mfma", "spectra", "fft"])
 def test_gcc_phat_with_a_silent_channel(gpu_device, kernel, monkeypatch):
     """X = 0 must give R / |R| = 1 (np.exp(1j * np.angle(0))): pairs with the dead microphone are a unit pulse at lag 0,
     the other pairs are untouched.  (The kernel stores a zero phasor for such a channel and switches, per frame, to the
@@ -114,4 +115,25 @@ def test_gcc_phat_full_size_clip_and_kernel_variants(gpu_device, monkeypatch):
         ref = ofeat.gcc_phat_f64(excerpt.numpy())                         # [28, 64, 101]
         f0 = start // 480
         got = gcc[f0 + 2:f0 + 99].transpose(1, 2, 0)                      # frames whose 960 samples lie inside the excerpt
+        assert np.abs(got - ref[:, :, 2:99]).max() <= 1e-4
+
+
+def test_foa_intensity_full_size_clip(gpu_device):
+    """The FOA feature set at workload size: a 60 s 4-channel clip (3001 frames) through seld_foa_intensity -- excerpts
+    spread over the clip agree with the float64 oracle computed on their own samples (interior frames), the log-mel
+    channels of the same pass equal the plain log-mel call bit for bit, a planted W-X correlation shows in channel 0."""
+    import seld_native
+    pcm = ofeat.synth_pcm(31, 4, 1_440_000, "noise")
+    pcm[1] = 0.6 * pcm[0] + 0.4 * pcm[1]
+    dev = pcm.to(gpu_device)
+    feat = seld_native.spatial_features(dev, "logmel_iv")                 # [3001, 7, 64]
+    assert tuple(feat.shape) == (3001, 7, 64)
+    assert torch.equal(feat[:, :4], seld_native.logmel(dev, layout="tcf"))
+    iv = feat[:, 4:].cpu().numpy()                                        # [F, 3, 64]
+    assert np.isfinite(iv).all() and np.abs(iv[:, 0]).mean() > 0.05
+    for start in (0, 480 * 1458, 1_440_000 - 48_000):
+        excerpt = pcm[:, start:start + 48_000]
+        ref = ofeat.foa_intensity_f64(excerpt.numpy())                    # [3, 64, 101]
+        f0 = start // 480
+        got = iv[f0 + 2:f0 + 99].transpose(1, 2, 0)                       # frames whose 960 samples lie inside the excerpt
         assert np.abs(got - ref[:, :, 2:99]).max() <= 1e-4
