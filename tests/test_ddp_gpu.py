@@ -74,7 +74,17 @@ def test_train_model_shards_the_device_feed(gpu_device, tmp_path):
     assert len(a["train_losses"]) == 2 and all(0 < v < 1 for v in a["train_losses"])
 
 
+_runs = {}
+
+
 def _exchange_run(mode, port_base):
+    """One two-rank run of tests/ddp_step_worker.py per mode and test session (the runs are deterministic)."""
+    if mode not in _runs:
+        _runs[mode] = _exchange_run_uncached(mode, port_base)
+    return _runs[mode]
+
+
+def _exchange_run_uncached(mode, port_base):
     env = dict(os.environ, SELD_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     port = port_base + os.getpid() % 90
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
