@@ -15,8 +15,9 @@ PCM and metadata are already resident in HBM when the timed region starts:
   3. crop to 3000 aligned frames per clip, concatenate, cut 1920 windows of 250 frames / hop 50
      (dataset.py:243-317: 60 windows per clip, windows straddle clip boundaries as upstream)
   4. 60 optimiser iterations of 32 windows: window gather -> CRNN forward (bf16 autocast) ->
-     fused softmax-MSE loss -> backward -> (N > 1: all-reduce of the flat gradient buffers over RCCL) -> Adam;
-     after three eager iterations the iteration is a replayed HIP graph (seld_graph.py; trainer.train_model's own path).
+     fused softmax-MSE loss -> backward -> Adam; after three eager iterations the iteration is a replayed HIP graph
+     (seld_graph.py; trainer.train_model's own path).  N > 1: the backward pass is cut into stages, one graph each, and
+     the gradient buckets a stage completes are all-reduced over RCCL asynchronously while the next stages replay.
 clips/s = N * 32 * K / (max-over-ranks wall time); weak scaling (every rank has its own 32 clips).
 
 The JSON line also carries
@@ -27,6 +28,11 @@ The JSON line also carries
   roofline_model: the optimiser iterations against the dense bf16 MFMA peak (39.4 GFLOP/window for the CRNN);
   kernels       : every other hand-written kernel (conv tail, loss, window gather, BiGRU recurrence) at the
                   workload's shapes against the roofline that bounds it, timed after the timed region;
+  allreduce_overlap : N = 1: the data-parallel step's stage graphs replayed on this GPU without collectives, HIP events
+                  between the replays (duration of every stage, bytes of every gradient bucket, the window that hides its
+                  all-reduce); N > 1: true / false for the run, with `gradient_buckets`;
+  other_workloads : 2 warm-up + 3 timed steps each of the other BASELINE.json workloads (configs[2], configs[4] on one GPU,
+                  configs[3]'s per-GPU shard) in the same process, after the timed region -- never part of `value`;
   cpu_baseline  : the oracle (torch CPU restatement of the reference path) timed on this host's
                   cores on a bounded sample -- a reported, non-target number.
 

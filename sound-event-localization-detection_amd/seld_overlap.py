@@ -1,4 +1,4 @@
-"""Weight gradients on a side HIP stream, hidden under the BiGRU backward recurrences.
+"""Weight gradients on side HIP streams, hidden under the BiGRU backward recurrences and the convolution backward.
 
 The backward recurrence of a BiGRU layer (csrc/gru.hip) is a persistent kernel on 16 of the 256 CUs (one per
 direction and 4-sequence tile at batch 32) for ~365 us, and the chain head -> layer 1 -> layer 0 is serial: the
