@@ -133,8 +133,8 @@ def run_cnn_blocks(blocks, x):
                 # block -- GRU layer 0's weight gradients, carried over from the recurrent stage, are computed beside
                 # that block's data gradient and travel under the rest -- and at the encoder's output
                 if depth == len(blocks) - 2:
-                    x = seld_cut.boundary(x)
-        return seld_cut.boundary(x)
+                    x = seld_cut.boundary(x, level=2)
+        return seld_cut.boundary(x, level=1)
     for block in blocks:
         x = block(x)
     return x

@@ -91,7 +91,7 @@ class ResNet50Encoder(nn.Module):
             # Conformer + head gradients (72 MB bf16) travel under the whole encoder backward, layer4's (30 MB) under
             # layer3..stem
             import seld_cut
-            return seld_cut.boundary(self.layer4(seld_cut.boundary(x)))
+            return seld_cut.boundary(self.layer4(seld_cut.boundary(x, level=2)), level=1)
         return self.layer4(x)
 
 

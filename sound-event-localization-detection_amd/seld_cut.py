@@ -11,9 +11,15 @@ model marks with ``boundary(x)``:
 returns a detached leaf in place of ``x`` -- autograd stops there -- and remembers the pair; a later stage continues
 with ``torch.autograd.backward(x, leaf.grad)``.  Same kernels on the same numbers in the same order as the uncut
 backward pass, so the cut changes no result (tests/test_graph_gpu.py, tests/test_ddp_gpu.py)."""
+import os
+
 import torch
 
 _active = None
+# how fine the cut is: 1 = only the models' primary cut (between the recurrent / attention part and the encoder),
+# 2 = also the secondary ones (before the encoder's last block / layer4).  Config.ALLREDUCE_CUT_LEVELS via the trainer;
+# SELD_CUT_LEVELS overrides (developer A/B).
+levels = int(os.environ.get("SELD_CUT_LEVELS", "2"))
 
 
 class recording:
@@ -31,8 +37,8 @@ class recording:
         return False
 
 
-def boundary(x):
-    if _active is None or not torch.is_grad_enabled() or not x.requires_grad:
+def boundary(x, level=1):
+    if _active is None or level > levels or not torch.is_grad_enabled() or not x.requires_grad:
         return x
     leaf = x.detach().requires_grad_(True)
     _active.append((x, leaf))
