@@ -110,6 +110,9 @@ class Config:
     OVERLAP_ALLREDUCE = True    # data parallel + GRAPH_STEP: the backward pass is cut at the models' seld_cut.boundary points and
                                 # captured as one graph per stage; the gradients a stage completes are all-reduced (RCCL,
                                 # asynchronously) while the next stages run.  False: one graph, then one blocking exchange
+    ALLREDUCE_CUT_LEVELS = 2    # 1: cut the backward pass only between the recurrent / attention part and the encoder; 2: also
+                                # before the encoder's last block (one more bucket under way, ~50 us more per iteration:
+                                # tools/bench_stages.py measured 3.62 ms as one graph, 3.67 / 3.72 / 3.77 ms with 0 / 1 / 2 cuts)
     GRAD_REDUCE_DTYPE = "param"  # wire dtype of that exchange: "param" = the bf16 working-weight gradients are summed in bf16
                                 # (half the xGMI bytes), "fp32" = cast into fp32 buffers first (what an autocast port of the
                                 # reference would reduce; the buffers double as the fp32 masters' gradients)

@@ -108,6 +108,9 @@ def prepare_model_for_device(model, device):
         for module in model.modules():
             if isinstance(module, SeldGRU) and SeldGRU.fused_enabled:
                 seld_gru.pack_parameters(module)
+        if os.environ.get("SELD_CUT_LEVELS") is None:
+            import seld_cut
+            seld_cut.levels = int(getattr(config, "ALLREDUCE_CUT_LEVELS", 2))
         import seld_tuned
         seld_tuned.enable(device, bool(getattr(config, "TUNED_GEMMS", True)))
     SMRSELDLoss.fused_enabled = bool(getattr(config, "FUSED_LOSS", True))
