@@ -106,6 +106,9 @@ def parse_args():
                     help="labels by the Gaussian box rasteriser (smrl_seld_gaussian.py:397-534, BASELINE configs[4])")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the short runs of the other BASELINE workloads after the timed region (`other_workloads`)")
+    ap.add_argument("--rehearsal-clips", type=int, default=None,
+                    help="clips per step of a --rehearse-gloo run (default 32 like a measurement; the GPU tests use 8: the "
+                         "gradients of every iteration travel through the host there)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N ranks share the visible GPU(s) over gloo (DDP rehearsal on a one-GPU box; not a measurement)")
     return ap.parse_args()
@@ -523,7 +526,12 @@ WORKLOAD_CONFIG = {OTHER_WORKLOADS[0][0]: "BASELINE configs[2]",
 
 
 def main():
+    global CLIPS_PER_STEP
     args = parse_args()
+    if args.rehearsal_clips is not None:
+        if not (args.rehearse_gloo or os.environ.get("SELD_DIST_BACKEND") == "gloo"):
+            raise SystemExit("--rehearsal-clips only applies to the gloo rehearsal (a measurement is 32 clips per step)")
+        CLIPS_PER_STEP = int(args.rehearsal_clips)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

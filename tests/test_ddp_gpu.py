@@ -18,7 +18,7 @@ def test_two_ranks_share_one_gpu_and_stay_in_sync(gpu_device):
     env = dict(os.environ, SELD_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     port = 29600 + os.getpid() % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"]
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--rehearsal-clips", "8"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -39,7 +39,8 @@ def test_bench_launches_its_own_ranks_or_refuses(gpu_device):
                          env=env, capture_output=True, text=True, timeout=300, cwd=str(ROOT))
     assert out.returncode == 2 and "--rehearse-gloo" in out.stderr and not out.stdout.strip()
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-                          "--rehearse-gloo"], env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+                          "--rehearse-gloo", "--rehearsal-clips", "8"], env=env, capture_output=True, text=True, timeout=900,
+                         cwd=str(ROOT))
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["rehearsal"] is True and line["config"]["backend"] == "gloo"
