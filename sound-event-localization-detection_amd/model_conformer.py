@@ -55,14 +55,42 @@ class MultiHeadSelfAttention(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.norm = nn.LayerNorm(d_model)
 
+    fused_qkv = True        # Config.FUSED_QKV via trainer.prepare_model_for_device
+
     def _heads(self, proj, x):
         b, t, _ = x.shape
         return proj(x).view(b, t, self.n_heads, self.head_dim).transpose(1, 2)      # [B, H, T, Dh]
 
+    def pack_parameters(self):
+        """q / k / v weights (and biases) as consecutive slices of one buffer: the three projections of the same input are
+        then ONE GEMM on a view (seld_pack.py); names, values and ``state_dict`` unchanged."""
+        import seld_pack
+        seld_pack.pack((self.w_q.weight, self.w_k.weight, self.w_v.weight))
+        seld_pack.pack((self.w_q.bias, self.w_k.bias, self.w_v.bias))
+
+    def _qkv(self, y):
+        """The three projections model_conformer.py:52-55 applies to the same normalised input, as one [3D, D] GEMM
+        forward, one data-gradient GEMM and one weight-gradient product backward (six launches fewer per block and
+        direction at sizes where a launch is all a GEMM costs: 8000 x 256 x 256)."""
+        import seld_pack
+        from seld_linear import _Linear
+        b, t, d = y.shape
+        w = seld_pack.join(self.w_q.weight, self.w_k.weight, self.w_v.weight)
+        bias = seld_pack.join(self.w_q.bias, self.w_k.bias, self.w_v.bias)
+        qkv = _Linear.apply(y, w, bias).view(b, t, 3, self.n_heads, self.head_dim)
+        q, k, v = qkv.unbind(dim=2)
+        return q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)              # [B, H, T, Dh] views
+
     def forward(self, x):
         b, t, d = x.shape
         y = layer_norm_of(self.norm, x)
-        q, k, v = self._heads(self.w_q, y), self._heads(self.w_k, y), self._heads(self.w_v, y)
+        import seld_pack
+        if (self.fused_qkv and y.is_cuda and y.dtype in (torch.float32, torch.bfloat16)
+                and seld_pack.adjacent(self.w_q.weight, self.w_k.weight, self.w_v.weight)
+                and seld_pack.adjacent(self.w_q.bias, self.w_k.bias, self.w_v.bias)):
+            q, k, v = self._qkv(y)
+        else:
+            q, k, v = self._heads(self.w_q, y), self._heads(self.w_k, y), self._heads(self.w_v, y)
         ctx = F.scaled_dot_product_attention(q, k, v, dropout_p=self.dropout.p if self.training else 0.0)
         ctx = ctx.transpose(1, 2).reshape(b, t, d)
         return x + self.dropout(self.w_o(ctx))

@@ -116,30 +116,7 @@ class _BiGRULayer(torch.autograd.Function):
             dw_ih.view_as(dw_ih), db_ih.to(t_bih), dw_hh.view_as(dw_hh), db_hh.to(t_bhh), None, None
 
 
-class _Joined(torch.autograd.Function):
-    """torch.cat((a, b), 0) for two parameters that are ADJACENT slices of one buffer (SeldGRU.pack_parameters):
-    the concatenation is a view (no copy forward, no copy backward)."""
-
-    @staticmethod
-    def forward(ctx, a, b):
-        ctx.rows = a.shape[0]
-        out = a.new_empty(0)
-        out.set_(a.untyped_storage(), a.storage_offset(), (a.shape[0] + b.shape[0],) + tuple(a.shape[1:]))
-        return out
-
-    @staticmethod
-    def backward(ctx, grad):
-        return grad[:ctx.rows], grad[ctx.rows:]
-
-
-def _adjacent(a, b):
-    return (a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous() and a.shape[1:] == b.shape[1:]
-            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
-            and b.storage_offset() == a.storage_offset() + a.numel())
-
-
-def _join(a, b):
-    return _Joined.apply(a, b) if _adjacent(a, b) else torch.cat((a, b), dim=0)
+from seld_pack import adjacent as _adjacent, join as _join, pack as _pack   # noqa: E402  (shared with the attention layers)
 
 
 def pack_parameters(module):
@@ -149,13 +126,7 @@ def pack_parameters(module):
     with torch.no_grad():
         for layer in range(module.num_layers):
             for kind in ("weight_ih", "bias_ih", "weight_hh", "bias_hh"):
-                a = getattr(module, f"{kind}_l{layer}")
-                b = getattr(module, f"{kind}_l{layer}_reverse")
-                if _adjacent(a, b):
-                    continue
-                flat = torch.cat((a.detach().reshape(-1), b.detach().reshape(-1)))
-                a.data = flat[:a.numel()].view_as(a)
-                b.data = flat[a.numel():].view_as(b)
+                _pack((getattr(module, f"{kind}_l{layer}"), getattr(module, f"{kind}_l{layer}_reverse")))
 
 
 def bigru_forward(module, x, feature_cf=None, overlap=False, need_hn=True):

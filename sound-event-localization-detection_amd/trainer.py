@@ -105,9 +105,14 @@ def prepare_model_for_device(model, device):
         if os.environ.get("SELD_OVERLAP") is None:
             import seld_overlap
             seld_overlap.enabled = bool(getattr(config, "OVERLAP_WEIGHT_GRADS", True))
+        import model_conformer
+        model_conformer.MultiHeadSelfAttention.fused_qkv = bool(getattr(config, "FUSED_QKV", True)) and \
+            os.environ.get("SELD_FUSED_QKV", "1") != "0"            # developer switch for A/B runs
         for module in model.modules():
             if isinstance(module, SeldGRU) and SeldGRU.fused_enabled:
                 seld_gru.pack_parameters(module)
+            if isinstance(module, model_conformer.MultiHeadSelfAttention):
+                module.pack_parameters()
         if os.environ.get("SELD_CUT_LEVELS") is None:
             import seld_cut
             seld_cut.levels = int(getattr(config, "ALLREDUCE_CUT_LEVELS", 2))
@@ -365,6 +370,9 @@ def enable_master_weights(model, device):
                 names[f"{mod_name}.{pname}" if mod_name else pname] = master
         if isinstance(module, SeldGRU) and SeldGRU.fused_enabled:
             seld_gru.pack_parameters(module)          # keep (forward, reverse) pairs adjacent in their new dtype
+    for module in target.modules():                   # q / k / v of the attention layers likewise (seld_pack.py)
+        if type(module).__name__ == "MultiHeadSelfAttention" and hasattr(module, "pack_parameters"):
+            module.pack_parameters()
     target._seld_master_weights = (low, masters, names)
     return True
 

@@ -70,3 +70,32 @@ def test_column_sums_match_fp64(gpu_device, rows, cols, dtype):
         again = torch.empty_like(out)
         seld_native.column_sums(g, again)
         assert torch.equal(out, again)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_qkv_projection_matches_three_linears(gpu_device, dtype):
+    """MultiHeadSelfAttention (model_conformer.py:31-69) with its q / k / v projections as ONE GEMM on packed parameters
+    (seld_pack.py) against the same module running three Linears: outputs and every gradient agree (same dot products,
+    possibly another summation order inside the library GEMM)."""
+    from model_conformer import MultiHeadSelfAttention
+    torch.manual_seed(0)
+    attn = MultiHeadSelfAttention(256, n_heads=4, dropout=0.0).to(gpu_device)
+    attn.pack_parameters()
+    x = torch.randn(8, 250, 256, device=gpu_device)
+    results = {}
+    for fused in (True, False):
+        MultiHeadSelfAttention.fused_qkv = fused
+        for p in attn.parameters():
+            p.grad = None
+        xin = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+            y = attn(xin)
+        y.float().square().mean().backward()
+        results[fused] = (y.detach().float(), xin.grad.float(), {n: p.grad.float().clone() for n, p in attn.named_parameters()})
+    MultiHeadSelfAttention.fused_qkv = True
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
+    (y1, dx1, g1), (y0, dx0, g0) = results[True], results[False]
+    assert (y1 - y0).abs().max().item() <= tol * y0.abs().max().item()
+    assert (dx1 - dx0).norm().item() <= tol * dx0.norm().item()
+    for n in g0:
+        assert (g1[n] - g0[n]).norm().item() <= tol * max(g0[n].norm().item(), 1e-12), n
