@@ -164,7 +164,17 @@ class SELD_Conformer(nn.Module):
 
     def forward(self, x):
         batch, frames = x.shape[0], x.shape[1]
-        y = self.proj(run_cnn_encoder(self.cnn_blocks, x))
+        y = None
+        if x.is_cuda:
+            from model_crnn import run_cnn_blocks
+            from seld_linear import linear_on_channels_last_features
+            enc = run_cnn_blocks(self.cnn_blocks, x)                       # [B, C, T, F], channels-last memory
+            y = linear_on_channels_last_features(self.proj, enc)           # no feature copy: the weight's columns move
+            if y is None:
+                enc = enc.permute(0, 2, 1, 3)
+                y = self.proj(enc.reshape(batch, frames, -1))
+        if y is None:
+            y = self.proj(run_cnn_encoder(self.cnn_blocks, x))
         for block in self.conformer_blocks:
             y = block(y)
         return run_head(self.fnn, y).view(batch, frames, self.grid_cells, self.num_classes)

@@ -130,8 +130,13 @@ class SELD_ResNet50_Conformer(nn.Module):
                 y = self.encoder(y)                                  # [B, 2048, T, F/32]
         else:
             y = self.encoder(y)
-        y = y.permute(0, 2, 1, 3).reshape(batch, frames, -1)
-        y = self.dropout(self.proj(y))
+        proj = None
+        if y.is_cuda:
+            from seld_linear import linear_on_channels_last_features
+            proj = linear_on_channels_last_features(self.proj, y)          # no 65 MB feature copy: the weight's columns move
+        if proj is None:
+            proj = self.proj(y.permute(0, 2, 1, 3).reshape(batch, frames, -1))
+        y = self.dropout(proj)
         for block in self.conformer_blocks:
             y = block(y)
         return run_head(self.head, y).view(batch, frames, self.grid_cells, self.num_classes)

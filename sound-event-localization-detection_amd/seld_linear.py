@@ -174,3 +174,20 @@ class SeldLinear(nn.Linear):
                 return _Linear.apply(x, late[0], late[1] if len(late) > 1 else None, True)
             return _Linear.apply(x, self.weight, self.bias)
         return super().forward(x)
+
+
+def linear_on_channels_last_features(linear, y):
+    """``linear(features)`` for an encoder output y [B, C, T, F] whose MEMORY is channels-last, i.e. [B][T][F][C]: the
+    reference flattens the features channel-major -- ``y.permute(0, 2, 1, 3).reshape(B, T, C * F)``, model_conformer.py:196-200,
+    resnet50_model.py:128-133: a 65 MB copy each way at batch 32 -- but the (frequency, channel)-ordered vector is a VIEW of
+    that memory, so the COLUMNS of the (small) weight are permuted instead; same dot products.  Returns None when the
+    layout does not allow it (the caller then takes the reference's order)."""
+    if not (enabled and y.is_cuda and y.dim() == 4 and y.is_contiguous(memory_format=torch.channels_last)
+            and y.dtype in (torch.float32, torch.bfloat16)):
+        return None
+    b, c, t, f = y.shape
+    if linear.in_features != c * f:
+        return None
+    feats = y.permute(0, 2, 3, 1).reshape(b, t, f * c)                       # a view: (f, c) order
+    w = linear.weight.view(linear.out_features, c, f).transpose(1, 2).reshape(linear.out_features, f * c)
+    return _Linear.apply(feats, w, linear.bias)
