@@ -96,6 +96,8 @@ class Config:
                                 # fewer GPU microseconds but more host work; "auto" = always under GRAPH_STEP (no host work
                                 # per iteration), else modules with d_model >= 512 (eager: +3 % on the ResNet50-Conformer,
                                 # -7 % on the host-bound d_model-256 Conformer)
+    CONV1X1_AS_GEMM = True      # ResNet bottlenecks: the 1x1 / stride-1 convolutions as GEMMs on the channels-last rows
+                                # (hipBLASLt forward / data gradient, split-K weight gradient) instead of MIOpen's
     FUSED_QKV = True            # Conformer self-attention: the q / k / v projections of the same input as ONE GEMM on packed
                                 # parameters (seld_pack.py), forward and backward
     FUSED_LAYERNORM = True      # head: LayerNorm -> ReLU in one kernel, activations stay bf16 (csrc/layernorm.hip)

@@ -191,3 +191,22 @@ def linear_on_channels_last_features(linear, y):
     feats = y.permute(0, 2, 3, 1).reshape(b, t, f * c)                       # a view: (f, c) order
     w = linear.weight.view(linear.out_features, c, f).transpose(1, 2).reshape(linear.out_features, f * c)
     return _Linear.apply(feats, w, linear.bias)
+
+
+conv1x1_as_gemm = True        # Config.CONV1X1_AS_GEMM via trainer.prepare_model_for_device
+
+
+def conv1x1(conv, x):
+    """``conv(x)`` for a 1x1 / stride-1 / bias-free nn.Conv2d on a channels-last activation (the first and third
+    convolution of every ResNet bottleneck, resnet50_model.py:30-52).  In channels-last memory x [B, C, T, F] IS a row-major
+    [B*T*F, C] matrix, so the convolution is a plain GEMM on views: forward and data gradient through hipBLASLt, the
+    weight gradient as the split-K product of ``tall_product`` with its chunk sum queued with the Linears' (MIOpen runs
+    these as CK batched split-K GEMMs with a memset each: 27 + 65 launches, 1.8 ms of a ResNet50-Conformer iteration)."""
+    if not (conv1x1_as_gemm and enabled and x.is_cuda and x.dim() == 4 and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
+            and x.is_contiguous(memory_format=torch.channels_last) and x.dtype in (torch.float32, torch.bfloat16)):
+        return conv(x)
+    b, c, t, f = x.shape
+    x2 = x.permute(0, 2, 3, 1).reshape(b * t * f, c)                       # a view of the channels-last memory
+    y2 = _Linear.apply(x2, conv.weight.reshape(conv.out_channels, c), None)
+    return y2.view(b, t, f, conv.out_channels).permute(0, 3, 1, 2)         # channels-last [B, C_out, T, F]

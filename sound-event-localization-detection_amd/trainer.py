@@ -105,6 +105,9 @@ def prepare_model_for_device(model, device):
         if os.environ.get("SELD_OVERLAP") is None:
             import seld_overlap
             seld_overlap.enabled = bool(getattr(config, "OVERLAP_WEIGHT_GRADS", True))
+        import seld_linear
+        seld_linear.conv1x1_as_gemm = bool(getattr(config, "CONV1X1_AS_GEMM", True)) and \
+            os.environ.get("SELD_CONV1X1_GEMM", "1") != "0"         # developer switch for A/B runs
         import model_conformer
         model_conformer.MultiHeadSelfAttention.fused_qkv = bool(getattr(config, "FUSED_QKV", True)) and \
             os.environ.get("SELD_FUSED_QKV", "1") != "0"            # developer switch for A/B runs
