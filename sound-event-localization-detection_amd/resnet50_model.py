@@ -36,12 +36,8 @@ class Bottleneck(nn.Module):
         shortcut = x if self.downsample is None else self.downsample(x)
         if x.is_cuda:
             import seld_convtail as tail           # fused BatchNorm -> [+ shortcut] -> ReLU (csrc/convtail.hip)
-            from seld_linear import conv1x1, conv1x1_fork
-            forked = conv1x1_fork(self.conv1, x) if self.downsample is None else None
-            if forked is not None:                # identity shortcut: both uses of x meet in one autograd node
-                y, shortcut = forked
-            else:
-                y = conv1x1(self.conv1, x)        # 1x1 convolutions: GEMMs on the channels-last rows
+            from seld_linear import conv1x1
+            y = conv1x1(self.conv1, x)            # 1x1 convolutions: GEMMs on the channels-last rows
             y = tail.bn_relu(self.bn1, y) if tail.bn_applicable(self.bn1, y) else self.relu(self.bn1(y))
             y = conv3x3(self.conv2, y)            # stride-1 3x3: data gradient as a forward convolution
             y = tail.bn_relu(self.bn2, y) if tail.bn_applicable(self.bn2, y) else self.relu(self.bn2(y))

@@ -210,56 +210,3 @@ def conv1x1(conv, x):
     x2 = x.permute(0, 2, 3, 1).reshape(b * t * f, c)                       # a view of the channels-last memory
     y2 = _Linear.apply(x2, conv.weight.reshape(conv.out_channels, c), None)
     return y2.view(b, t, f, conv.out_channels).permute(0, 3, 1, 2)         # channels-last [B, C_out, T, F]
-
-
-class _Conv1x1Fork(torch.autograd.Function):
-    """(conv1(x), x) for the entry of a ResNet bottleneck with an identity shortcut (resnet50_model.py:30-52): x feeds the
-    first 1x1 convolution AND the residual add at the block's end, so autograd would ADD the two gradients that come back
-    (one elementwise pass over the block's input per block: 13 of them, 65 MB each in layer1).  Here both gradients
-    arrive at one node and the data-gradient GEMM accumulates onto the shortcut's gradient in its epilogue
-    (``addmm``: dx = d_shortcut + dy W)."""
-
-    @staticmethod
-    def forward(ctx, x, weight):
-        b, c, t, f = x.shape
-        cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
-        with torch.autocast(device_type="cuda", enabled=False):
-            xc = x.permute(0, 2, 3, 1).reshape(b * t * f, c).to(cdt)             # a view of the channels-last memory
-            wc = weight.to(cdt)
-            y2 = F.linear(xc, wc)
-        ctx.save_for_backward(xc, wc)
-        ctx.meta = (x.shape, x.dtype, weight.dtype)
-        return y2.view(b, t, f, wc.shape[0]).permute(0, 3, 1, 2), x.view_as(x)
-
-    @staticmethod
-    def backward(ctx, dy, dshort):
-        xc, wc = ctx.saved_tensors
-        (b, c, t, f), x_dtype, w_dtype = ctx.meta
-        with torch.autocast(device_type="cuda", enabled=False):
-            g2 = dy.permute(0, 2, 3, 1).reshape(b * t * f, wc.shape[0]).to(xc.dtype)
-            dx2 = None
-            if ctx.needs_input_grad[0]:
-                if dshort is not None and dshort.dtype == xc.dtype and dshort.is_contiguous(memory_format=torch.channels_last):
-                    dx2 = torch.addmm(dshort.permute(0, 2, 3, 1).reshape(b * t * f, c), g2, wc)
-                else:
-                    dx2 = g2 @ wc
-                    if dshort is not None:
-                        dx2 = dx2 + dshort.permute(0, 2, 3, 1).reshape(b * t * f, c).to(dx2.dtype)
-            dw = tall_product(g2, xc, out_dtype=w_dtype, queue=True) if ctx.needs_input_grad[1] else None
-            if dw is not None and _batch is not None:
-                dw = dw.view_as(dw)                          # possibly queued: a fresh alias for autograd
-        dx = None if dx2 is None else dx2.view(b, t, f, c).permute(0, 3, 1, 2)
-        if dx is not None and dx.dtype != x_dtype:
-            dx = dx.to(x_dtype)
-        return dx, dw
-
-
-def conv1x1_fork(conv, x):
-    """``(conv(x), x)`` with the gradient accumulation of the two uses of x folded into the data-gradient GEMM, or None
-    when ``conv1x1`` would not apply (the caller then uses x twice the ordinary way)."""
-    if not (conv1x1_as_gemm and enabled and x.is_cuda and x.dim() == 4 and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
-            and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
-            and x.is_contiguous(memory_format=torch.channels_last) and x.dtype in (torch.float32, torch.bfloat16)
-            and torch.is_grad_enabled() and x.requires_grad):
-        return None
-    return _Conv1x1Fork.apply(x, conv.weight.reshape(conv.out_channels, x.shape[1]))
