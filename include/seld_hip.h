@@ -163,6 +163,19 @@ int seld_softmax_mse(const void* logits, int logits_is_bf16, const uint16_t* mas
  * touched.  n must be a multiple of 8; data bf16 when is_bf16, else fp32, 16-byte aligned. */
 int seld_scale_by_device_scalar(void* data, int is_bf16, int64_t n, const float* scale, void* stream);
 
+/* The optimiser step of trainer.py:112-116,179 (torch.optim.Adam with weight_decay as L2 added to the gradient; amsgrad off)
+ * for a LIST of tensors in one launch per 48 tensors, arithmetic of the framework's fused kernel in fp32:
+ *   g = grad * grad_scale + weight_decay * p;  m += (1 - beta1)(g - m);  v = beta2 v + (1 - beta2) g g;
+ *   p -= (lr / (1 - beta1^step)) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ * grad[k]: bf16 when grad_is_bf16[k] (the gradient of a bf16 working weight: no separate cast), else fp32; param / exp_avg /
+ * exp_avg_sq fp32; low_bf16[k]: the bf16 working copy rewritten from the new master, or NULL.  All tensors of an entry
+ * share one memory layout (the kernel walks the storage).  lr and step are DEVICE scalars (step = the count of THIS
+ * update, i.e. already incremented).  HOST arrays of device addresses / lengths, passed to the kernel by value. */
+int seld_multi_adam(const void* const* grad, const int32_t* grad_is_bf16, float* const* param, float* const* exp_avg,
+                    float* const* exp_avg_sq, void* const* low_bf16, const int64_t* lengths, int count, const float* lr,
+                    const float* step, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                    void* stream);
+
 /* One launch per 96 tensors casts a list of tensors (the fp32-master / bf16-working-weight mode of the trainer):
  * src / dst are HOST arrays of `count` device addresses, lengths a HOST array of element counts (the descriptors are
  * passed to the kernel by value).  bf16_to_fp32 != 0: bf16 sources -> fp32 destinations (gradients); 0: fp32 -> bf16

@@ -108,6 +108,9 @@ class Config:
     MASTER_WEIGHTS = True       # bf16 runs: the conv / Linear / GRU weight matrices live in the model as bf16 working
                                 # copies of fp32 masters owned by the optimiser (same values autocast would cast to
                                 # every iteration, without ~40-340 cast kernels per iteration; bf16 gradient all-reduce)
+    FUSED_ADAM_KERNEL = True    # master-weight mode, captured steps: the whole Adam update incl. the bf16 gradient read and the
+                                # bf16 working-copy write as one multi-tensor launch (csrc/adam.hip) instead of cast + the
+                                # framework's fused Adam + cast
     GRAPH_STEP = True           # one optimiser iteration = one replayed HIP graph per input shape (seld_graph.py): the eager
                                 # loop spends ~3.5 ms of host time enqueueing ~300 launches per CRNN iteration; data
                                 # parallel: graph (forward + backward) -> flat all-reduce -> graph (Adam)

@@ -84,6 +84,8 @@ def _declare(lib):
     lib.seld_gru_dwhh_finish.argtypes = [_ptr, _ptr, _int, _i64, _i64, _ptr, _int, _ptr]
     lib.seld_column_sums.argtypes = [_ptr, _int, _i64, _i64, _ptr, _ptr, _int, _ptr]
     _pp, _pi64, _pi32 = ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32)
+    _f = ctypes.c_float
+    lib.seld_multi_adam.argtypes = [_pp, _pi32, _pp, _pp, _pp, _pp, _pi64, _int, _ptr, _ptr, _f, _f, _f, _f, _f, _ptr]
     lib.seld_multi_sum_chunks.argtypes = [_pp, _pp, _pi64, _pi32, _pi32, _int, _ptr]
     lib.seld_multi_column_sums_scratch.argtypes = [_pi64, _pi64, _int, _pi64]
     lib.seld_multi_column_sums.argtypes = [_pp, _pp, _pi64, _pi64, _pi32, _int, _ptr, _i64, _ptr]
@@ -536,6 +538,51 @@ def multi_cast(srcs, dsts, cache=None) -> bool:
         cache["key"], cache["args"] = key, (src, dst, lengths, n, int(to_float))
     with _device_guard(ensure_init(device)):
         check(load_library().seld_multi_cast(src, dst, lengths, n, int(to_float), _stream_ptr(device)), "seld_multi_cast")
+    return True
+
+
+def multi_adam(grads, params, exp_avgs, exp_avg_sqs, lows, lr: torch.Tensor, step: torch.Tensor, beta1: float, beta2: float,
+               eps: float, weight_decay: float, grad_scale: float = 1.0, cache=None) -> bool:
+    """One Adam update (csrc/adam.hip; the arithmetic of torch's fused Adam, L2 weight decay) of fp32 ``params`` from
+    ``grads`` (bf16 or fp32, same layout as their parameter), rewriting the bf16 working copies ``lows[i]`` (or None) from
+    the new values; ``lr`` / ``step`` are fp32 device scalars (``step`` already incremented).  Returns False -- having done
+    nothing -- when a tensor does not qualify (layout / dtype), so that the caller can take the framework's path.
+    ``cache``: dict of a caller that passes the same lists every iteration (descriptor arrays reused while no address
+    changed)."""
+    n = len(params)
+    if n == 0:
+        return True
+    key = None
+    if cache is not None:
+        key = tuple(t.data_ptr() for t in grads) + tuple(t.data_ptr() for t in params) + \
+            tuple(0 if t is None else t.data_ptr() for t in lows)
+        if cache.get("key") == key:
+            args = cache["args"]
+        else:
+            args = None
+    else:
+        args = None
+    device = params[0].device
+    if args is None:
+        for g, p, m, v, lo in zip(grads, params, exp_avgs, exp_avg_sqs, lows):
+            if not (p.is_cuda and p.dtype == torch.float32 and m.dtype == torch.float32 and v.dtype == torch.float32
+                    and g.dtype in (torch.float32, torch.bfloat16) and _dense_like(g, p) and _dense_like(m, p)
+                    and _dense_like(v, p) and (lo is None or (lo.dtype == torch.bfloat16 and _dense_like(lo, p)))):
+                return False
+        args = ((ctypes.c_void_p * n)(*[g.data_ptr() for g in grads]),
+                (ctypes.c_int32 * n)(*[int(g.dtype == torch.bfloat16) for g in grads]),
+                (ctypes.c_void_p * n)(*[p.data_ptr() for p in params]),
+                (ctypes.c_void_p * n)(*[m.data_ptr() for m in exp_avgs]),
+                (ctypes.c_void_p * n)(*[v.data_ptr() for v in exp_avg_sqs]),
+                (ctypes.c_void_p * n)(*[0 if lo is None else lo.data_ptr() for lo in lows]),
+                (ctypes.c_int64 * n)(*[p.numel() for p in params]))
+        if cache is not None:
+            cache["key"], cache["args"] = key, args
+    if not (lr.is_cuda and step.is_cuda and lr.dtype == torch.float32 and step.dtype == torch.float32):
+        return False
+    with _device_guard(ensure_init(device)):
+        check(load_library().seld_multi_adam(*args, n, _p(lr), _p(step), float(beta1), float(beta2), float(eps),
+                                             float(weight_decay), float(grad_scale), _stream_ptr(device)), "seld_multi_adam")
     return True
 
 

@@ -410,14 +410,76 @@ class MasterWeightAdam(torch.optim.Adam):
         super().__init__(list(masters) + list(others), **kwargs)
         self._low, self._masters, self._others = list(low), list(masters), list(others)
         self.fused_casts = self.fallback_casts = 0        # how often the one-launch casts applied (diagnostics)
+        self.own_steps = 0                                # updates done by csrc/adam.hip
+        self._uniform_steps = True                        # every parameter has been updated in every step so far
+        self._adam_cache = {}
+        if os.environ.get("SELD_OWN_ADAM") == "0":
+            self.own_kernel = False
         self._grad_cast_cache, self._weight_cast_cache = {}, {}
         for m in self._masters:
             m.grad = torch.zeros_like(m)
 
+    own_kernel = True         # Config.FUSED_ADAM_KERNEL via make_optimizer; SELD_OWN_ADAM=0 switches it off (developer A/B)
+
+    def _own_step(self):
+        """The whole update as ONE multi-tensor launch per 48 tensors (csrc/adam.hip): the bf16 gradients are read as they
+        are and the bf16 working copies written from the new masters in the same pass -- 28 B per parameter instead of the
+        40 B of cast + fused Adam + cast.  Same arithmetic as the framework's fused Adam; the state keeps its format
+        (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``), so ``state_dict`` is unchanged.  Returns False when the
+        call does not qualify (then the three-launch path below runs)."""
+        import seld_native
+        group = self.param_groups[0]
+        lr = group["lr"]
+        if not (self.own_kernel and self._uniform_steps and len(self.param_groups) == 1 and isinstance(lr, torch.Tensor)
+                and lr.is_cuda and not group.get("amsgrad") and not group.get("maximize")
+                and not group.get("decoupled_weight_decay", False)):
+            return False
+        external = getattr(self, "external_master_grads", False)
+        params = self._masters + self._others
+        grads = [(m.grad if external else p.grad) for p, m in zip(self._low, self._masters)] + [p.grad for p in self._others]
+        if any(g is None for g in grads):
+            return False
+        steps = []
+        for p in params:
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            steps.append(st["step"])
+        lows = [p.data for p in self._low] + [None] * len(self._others)
+        exp_avgs = [self.state[p]["exp_avg"] for p in params]
+        exp_avg_sqs = [self.state[p]["exp_avg_sq"] for p in params]
+        # descriptor checks first (nothing may have run when this returns False): a dry call with count 0 is not
+        # available, so the eligibility test is multi_adam's own and the step counts are advanced only after it passed
+        beta1, beta2 = group["betas"]
+        if not self._adam_checked(grads, params, exp_avgs, exp_avg_sqs, lows):
+            return False
+        torch._foreach_add_(steps, 1)                 # every parameter's own counter, as the framework keeps them
+        ok = seld_native.multi_adam(grads, params, exp_avgs, exp_avg_sqs, lows, lr, steps[0], beta1, beta2, group["eps"],
+                                    group["weight_decay"], 1.0, self._adam_cache)
+        assert ok
+        self.fused_casts += 1
+        self.own_steps += 1
+        return True
+
+    def _adam_checked(self, grads, params, exp_avgs, exp_avg_sqs, lows):
+        import seld_native
+        for g, p, m, v, lo in zip(grads, params, exp_avgs, exp_avg_sqs, lows):
+            if not (p.is_cuda and p.dtype == torch.float32 and g.dtype in (torch.float32, torch.bfloat16)
+                    and seld_native._dense_like(g, p) and seld_native._dense_like(m, p) and seld_native._dense_like(v, p)
+                    and (lo is None or (lo.dtype == torch.bfloat16 and seld_native._dense_like(lo, p)))):
+                return False
+        return True
+
     @torch.no_grad()
     def step(self, closure=None):
         import seld_native
+        if self._own_step():
+            return None
         grads = [p.grad for p in self._low]
+        if any(p.grad is None for p in self._low + self._others):
+            self._uniform_steps = False           # the framework skips such parameters: their step counts fall behind
         master_grads = [m.grad for m in self._masters]
         if getattr(self, "external_master_grads", False):
             # the data-parallel exchange reduced in fp32: the masters' gradients ARE the all-reduced flat buffer's views
@@ -462,7 +524,10 @@ def make_optimizer(model, learning_rate, device, capturable=False):
     if state is not None:
         low_ids = {id(p) for p in state[0]}
         others = [p for p in model.parameters() if id(p) not in low_ids]
-        return MasterWeightAdam(state[0], state[1], others, **kwargs)
+        opt = MasterWeightAdam(state[0], state[1], others, **kwargs)
+        if not getattr(config, "FUSED_ADAM_KERNEL", True):
+            opt.own_kernel = False
+        return opt
     return torch.optim.Adam(model.parameters(), **kwargs)
 
 

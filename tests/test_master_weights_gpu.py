@@ -88,3 +88,70 @@ def test_multi_cast_descriptor_cache_follows_the_addresses(gpu_device):
     assert all(torch.equal(a.to(torch.bfloat16), b) for a, b in zip(src, low))
     src[1] = torch.randn(5, generator=g).to(gpu_device).double()        # wrong dtype: refused even with a cache
     assert not seld_native.multi_cast(src, low, cache)
+
+
+def test_own_adam_kernel_matches_the_framework_path(gpu_device):
+    """trainer.MasterWeightAdam with the one-launch update of csrc/adam.hip (bf16 gradients read directly, bf16 working
+    copies written in the same pass) against the same optimiser running cast + torch's fused Adam + cast, and against a
+    plain float64 statement of Adam with L2 weight decay (trainer.py:112-116 upstream): 8 steps on tensors of ragged and
+    channels-last shapes with a learning-rate change in between; state_dict in the framework's format."""
+    import trainer
+    torch.manual_seed(3)
+    shapes = [(9072, 512), (768, 256), (37,), (5, 3, 3, 3), (64, 4, 3, 3), (1,)]
+
+    def build(own):
+        g = torch.Generator().manual_seed(5)
+        low, masters, others = [], [], []
+        for i, shape in enumerate(shapes):
+            t = torch.randn(*shape, generator=g).to(gpu_device)
+            if len(shape) == 4:
+                t = t.contiguous(memory_format=torch.channels_last)
+            if i % 2 == 0:                                  # a bf16 working weight with its fp32 master
+                p = torch.nn.Parameter(t.to(torch.bfloat16))
+                low.append(p)
+                masters.append(t.clone())
+            else:                                           # a plain fp32 parameter
+                others.append(torch.nn.Parameter(t.clone()))
+        opt = trainer.MasterWeightAdam(low, masters, others, lr=torch.tensor(1e-2, device=gpu_device), weight_decay=1e-4,
+                                       fused=True, capturable=True)
+        opt.own_kernel = own
+        return opt
+
+    a, b = build(True), build(False)
+    ref = [t.detach().double().clone() for t in a._masters + [p.data for p in a._others]]
+    ref_m = [torch.zeros_like(t) for t in ref]
+    ref_v = [torch.zeros_like(t) for t in ref]
+    g = torch.Generator().manual_seed(9)
+    lr = 1e-2
+    for step in range(1, 9):
+        if step == 5:
+            lr = 2.5e-3
+            for opt in (a, b):
+                opt.param_groups[0]["lr"].fill_(lr)
+        grads = [torch.randn(*p.shape, generator=g) * 0.1 for p in a._low + a._others]
+        for opt in (a, b):
+            for p, gr in zip(opt._low + opt._others, grads):
+                gr = gr.to(gpu_device).to(p.dtype)
+                if p.dim() == 4:
+                    gr = gr.contiguous(memory_format=torch.channels_last)
+                p.grad = gr
+            opt.step()
+        for i, (p, gr) in enumerate(zip(a._low + a._others, grads)):
+            gq = gr.to(gpu_device).to(p.dtype).double() + 1e-4 * ref[i]
+            ref_m[i] = 0.9 * ref_m[i] + 0.1 * gq
+            ref_v[i] = 0.999 * ref_v[i] + 0.001 * gq * gq
+            ref[i] = ref[i] - (lr / (1 - 0.9 ** step)) * ref_m[i] / (ref_v[i].sqrt() / (1 - 0.999 ** step) ** 0.5 + 1e-8)
+    assert a.own_steps == 8 and b.own_steps == 0
+    mine = a._masters + [p.data for p in a._others]
+    theirs = b._masters + [p.data for p in b._others]
+    for i, (x, y, r) in enumerate(zip(mine, theirs, ref)):
+        scale = r.abs().max().item() + 1e-6
+        assert (x.double() - r).abs().max().item() <= 2e-6 * scale, i
+        assert (x - y).abs().max().item() <= 2e-6 * scale, i
+    for pa, m in zip(a._low, a._masters):                   # working copies = the masters rounded to bf16
+        assert torch.equal(pa.data, m.to(torch.bfloat16))
+    sa, sb = a.state_dict(), b.state_dict()
+    assert sa["state"].keys() == sb["state"].keys()
+    for k in sa["state"]:
+        assert set(sa["state"][k]) == {"step", "exp_avg", "exp_avg_sq"} and float(sa["state"][k]["step"]) == 8.0
+        assert (sa["state"][k]["exp_avg"] - sb["state"][k]["exp_avg"]).abs().max().item() <= 1e-6
