@@ -210,12 +210,6 @@ class GraphedTrainStep:
         self.exchange = world > 1 or split                       # flat buffers and separate graphs
         self.staged = self.exchange and bool(overlap_allreduce) and os.environ.get("SELD_OVERLAP_ALLREDUCE", "1") != "0"
         self.flat = FlatGradients(self.params, reduce_dtype, optimizer) if self.exchange else None
-        # One rank: the optimiser update of the layers above the models' primary cut (head, GRU / Conformer blocks) runs
-        # on a side stream WHILE the encoder's backward pass still runs (their gradients are final by then); the
-        # encoder's own update follows at the end.  Needs the one-launch Adam of trainer.MasterWeightAdam (csrc/adam.hip).
-        self.early_update = (not self.exchange and device.type == "cuda" and hasattr(optimizer, "step_subset")
-                             and os.environ.get("SELD_EARLY_UPDATE", "1") != "0")
-        self._early = None           # None: not decided yet (first iteration); then True / False
         self.shapes = {}             # key -> dict(calls, spec, labels, graphs, graph_b, out)
         self.pool = None
         self.captured = self.replays = self.eager_calls = 0
@@ -241,17 +235,10 @@ class GraphedTrainStep:
         if k == 0:
             for p in self.params:            # autograd hands its gradient tensors over (no accumulate kernels); under
                 p.grad = None                # capture they land in the graph's pool and are rewritten by every replay
-            cutting = self.staged or bool(self._early)
-            saved_levels = seld_cut.levels
-            if not self.staged:
-                seld_cut.levels = min(saved_levels, 1)        # the early update only uses the primary cut
-            try:
-                with seld_cut.recording() if cutting else nullcontext() as rec:
-                    with self.autocast():
-                        predictions = self.model(spec)
-            finally:
-                seld_cut.levels = saved_levels
-            self._cuts = list(rec.cuts) if cutting else []
+            with seld_cut.recording() if self.staged else nullcontext() as rec:
+                with self.autocast():
+                    predictions = self.model(spec)
+            self._cuts = list(rec.cuts) if self.staged else []
             total, term = self.criterion.loss_tensor(predictions, labels)
             self._out = (total.detach(), term.detach())
             root, grad = total, None
@@ -380,51 +367,8 @@ class GraphedTrainStep:
         e.record()
         return e
 
-    def _single_rank_iteration(self, spec, labels):
-        """One rank, no exchange: forward, backward, update -- with the update of the layers above the primary cut started
-        on side stream 2 as soon as their gradients are final (``early_update``).  Eager and captured runs execute this."""
-        import seld_overlap
-        last = self._stage(0, spec, labels)
-        if last:                                       # no cut recorded (first iteration, or a model without marks)
-            if self.early_update and self._early is None:
-                self._decide_early_update()
-            self._update()
-            return
-        unfinished = seld_overlap.carried_storages()
-        ready = {id(p) for p in self.params if p.grad is not None
-                 and p.grad.untyped_storage().data_ptr() not in unfinished}
-        main = torch.cuda.current_stream(self.device)
-        side = seld_overlap.side_stream(self.device, 2)
-        side.wait_stream(main)
-        seld_overlap._mark(self.device, 2)
-        with torch.cuda.stream(side):
-            done = self.optimizer.step_subset(ready)
-        k = 1
-        while not self._stage(k, spec, labels):
-            k += 1
-        seld_overlap._wait(self.device, 2)
-        if not done:                                   # the one-launch Adam does not apply here: one ordinary update
-            self.early_update, self._early = False, False
-            self._update()
-            return
-        rest = {id(p) for p in self.params} - ready
-        if not self.optimizer.step_subset(rest):
-            raise RuntimeError("the optimiser refused the second part of a split update")
-
-    def _decide_early_update(self):
-        """After the first (uncut) iteration: which parameters sit above the models' primary cut -- found by a dry
-        recording pass is not possible without running the model, so the decision uses the gradients' layouts of this
-        iteration (the one-launch Adam must accept every parameter) and the cut is recorded from the next forward on."""
-        ok = getattr(self.optimizer, "own_kernel", False) and all(p.grad is not None for p in self.params)
-        self._early = True if ok else False
-        if not ok:
-            self.early_update = False
-
     def _eager(self, spec, labels):
         self.eager_calls += 1
-        if not self.exchange:
-            self._single_rank_iteration(spec, labels)
-            return self._out
         works, k = [], 0
         while True:
             last = self._stage(k, spec, labels)
@@ -439,22 +383,14 @@ class GraphedTrainStep:
     def _capture(self, st, spec, labels):
         st["spec"], st["labels"] = spec.clone(), labels.clone()
         torch.cuda.synchronize(self.device)
-        if not self.exchange:                          # one rank: everything is one graph
-            graph = torch.cuda.CUDAGraph()
-            kwargs = {} if self.pool is None else {"pool": self.pool}
-            with torch.cuda.graph(graph, **kwargs):
-                self._single_rank_iteration(st["spec"], st["labels"])
-            if self.pool is None:
-                self.pool = graph.pool()
-            st["graphs"], st["graph_b"], st["out"] = [graph], None, self._out
-            self.captured += 1
-            return
         graphs, k = [], 0
         while True:
             graph = torch.cuda.CUDAGraph()
             kwargs = {} if self.pool is None else {"pool": self.pool}
             with torch.cuda.graph(graph, **kwargs):
                 last = self._stage(k, st["spec"], st["labels"])
+                if last and not self.exchange:
+                    self._update()
             if self.pool is None:
                 self.pool = graph.pool()
             graphs.append(graph)

@@ -421,11 +421,8 @@ class MasterWeightAdam(torch.optim.Adam):
 
     own_kernel = True         # Config.FUSED_ADAM_KERNEL via make_optimizer; SELD_OWN_ADAM=0 switches it off (developer A/B)
 
-    def _own_step(self, subset=None):
-        """``subset``: update only these parameters now (a set of ``id``s of model parameters; the captured step updates
-        the layers whose gradients are final while the rest of the backward pass still runs).
-
-        The whole update as ONE multi-tensor launch per 48 tensors (csrc/adam.hip): the bf16 gradients are read as they
+    def _own_step(self):
+        """The whole update as ONE multi-tensor launch per 48 tensors (csrc/adam.hip): the bf16 gradients are read as they
         are and the bf16 working copies written from the new masters in the same pass -- 28 B per parameter instead of the
         40 B of cast + fused Adam + cast.  Same arithmetic as the framework's fused Adam; the state keeps its format
         (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``), so ``state_dict`` is unchanged.  Returns False when the
@@ -438,12 +435,8 @@ class MasterWeightAdam(torch.optim.Adam):
                 and not group.get("decoupled_weight_decay", False)):
             return False
         external = getattr(self, "external_master_grads", False)
-        pairs = [(p, m) for p, m in zip(self._low, self._masters) if subset is None or id(p) in subset]
-        rest = [p for p in self._others if subset is None or id(p) in subset]
-        params = [m for _, m in pairs] + rest
-        grads = [(m.grad if external else p.grad) for p, m in pairs] + [p.grad for p in rest]
-        if not params:
-            return True
+        params = self._masters + self._others
+        grads = [(m.grad if external else p.grad) for p, m in zip(self._low, self._masters)] + [p.grad for p in self._others]
         if any(g is None for g in grads):
             return False
         steps = []
@@ -454,7 +447,7 @@ class MasterWeightAdam(torch.optim.Adam):
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             steps.append(st["step"])
-        lows = [p.data for p, _ in pairs] + [None] * len(rest)
+        lows = [p.data for p in self._low] + [None] * len(self._others)
         exp_avgs = [self.state[p]["exp_avg"] for p in params]
         exp_avg_sqs = [self.state[p]["exp_avg_sq"] for p in params]
         # descriptor checks first (nothing may have run when this returns False): a dry call with count 0 is not
@@ -463,20 +456,12 @@ class MasterWeightAdam(torch.optim.Adam):
         if not self._adam_checked(grads, params, exp_avgs, exp_avg_sqs, lows):
             return False
         torch._foreach_add_(steps, 1)                 # every parameter's own counter, as the framework keeps them
-        cache = self._adam_cache.setdefault(None if subset is None else (id(params[0]), len(params)), {})
         ok = seld_native.multi_adam(grads, params, exp_avgs, exp_avg_sqs, lows, lr, steps[0], beta1, beta2, group["eps"],
-                                    group["weight_decay"], 1.0, cache)
+                                    group["weight_decay"], 1.0, self._adam_cache)
         assert ok
-        if subset is None or len(params) >= (len(self._masters) + len(self._others) + 1) // 2:
-            self.fused_casts += 1                     # (counted once per iteration when the update runs in two parts)
-            self.own_steps += 1
+        self.fused_casts += 1
+        self.own_steps += 1
         return True
-
-    @torch.no_grad()
-    def step_subset(self, subset):
-        """Update the parameters whose ``id`` is in ``subset`` with the one-launch kernel; False (nothing done) when the
-        call does not qualify.  Every parameter must be updated exactly once per iteration by the caller."""
-        return self._own_step(subset)
 
     def _adam_checked(self, grads, params, exp_avgs, exp_avg_sqs, lows):
         import seld_native
