@@ -300,8 +300,8 @@ class GraphedTrainStep:
 
     def _update(self):
         if self.world > 1:
-            if hasattr(self.optimizer, "grad_scale"):          # trainer.MasterWeightAdam: 1 / world inside its update
-                self.optimizer.grad_scale = 1.0 / self.world
+            if hasattr(self.optimizer, "seld_grad_scale"):          # trainer.MasterWeightAdam: 1 / world inside its update
+                self.optimizer.seld_grad_scale = 1.0 / self.world
             else:
                 self.flat.scale(1.0 / self.world)
         self.optimizer.step()

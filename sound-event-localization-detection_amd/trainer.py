@@ -420,7 +420,7 @@ class MasterWeightAdam(torch.optim.Adam):
             m.grad = torch.zeros_like(m)
 
     own_kernel = True         # Config.FUSED_ADAM_KERNEL via make_optimizer; SELD_OWN_ADAM=0 switches it off (developer A/B)
-    grad_scale = 1.0          # every gradient is multiplied by this on its way into the update (data parallel: 1 / world,
+    seld_grad_scale = 1.0          # every gradient is multiplied by this on its way into the update (data parallel: 1 / world,
                               # set by seld_graph.GraphedTrainStep -- folded into the kernel instead of a pass over the buffers)
 
     def _own_step(self):
@@ -459,7 +459,7 @@ class MasterWeightAdam(torch.optim.Adam):
             return False
         torch._foreach_add_(steps, 1)                 # every parameter's own counter, as the framework keeps them
         ok = seld_native.multi_adam(grads, params, exp_avgs, exp_avg_sqs, lows, lr, steps[0], beta1, beta2, group["eps"],
-                                    group["weight_decay"], float(self.grad_scale), self._adam_cache)
+                                    group["weight_decay"], float(self.seld_grad_scale), self._adam_cache)
         assert ok
         self.fused_casts += 1
         self.own_steps += 1
@@ -482,11 +482,11 @@ class MasterWeightAdam(torch.optim.Adam):
         grads = [p.grad for p in self._low]
         if any(p.grad is None for p in self._low + self._others):
             self._uniform_steps = False           # the framework skips such parameters: their step counts fall behind
-        if self.grad_scale != 1.0:
+        if self.seld_grad_scale != 1.0:
             external = getattr(self, "external_master_grads", False)
             scaled = [g for g in ([m.grad for m in self._masters] if external else grads) + [p.grad for p in self._others]
                       if g is not None]
-            torch._foreach_mul_(scaled, float(self.grad_scale))
+            torch._foreach_mul_(scaled, float(self.seld_grad_scale))
         master_grads = [m.grad for m in self._masters]
         if getattr(self, "external_master_grads", False):
             # the data-parallel exchange reduced in fp32: the masters' gradients ARE the all-reduced flat buffer's views
