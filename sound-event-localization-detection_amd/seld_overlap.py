@@ -210,6 +210,7 @@ def defer(*params):
     """Aliases of ``params`` whose gradients may be produced by ``submit``-ted jobs."""
     del _pending[:]           # jobs of a backward pass that was abandoned by an exception: their graph is gone
     del _carried[:]
+    del _held[:]
     return _Deferred.apply(*params)
 
 
