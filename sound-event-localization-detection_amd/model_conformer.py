@@ -23,6 +23,24 @@ class Swish(nn.Module):
         return F.silu(x)            # x * sigmoid(x), model_conformer.py:6-8
 
 
+class _HalfStepResidual(torch.autograd.Function):
+    """x + scale * dropout(z) (the half-step residual of model_conformer.py:27-29) with the framework's own dropout
+    (``native_dropout``: the reference's random stream) but without the separate scaling kernels: forward = dropout +
+    one ``add(alpha=scale)``, backward = ONE masked scaling with the residual's factor folded into the dropout's."""
+
+    @staticmethod
+    def forward(ctx, x, z, p, scale):
+        d, mask = torch.ops.aten.native_dropout(z, p, True)
+        ctx.save_for_backward(mask)
+        ctx.factor = scale / (1.0 - p)
+        return torch.add(x, d, alpha=scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return g, torch.ops.aten.native_dropout_backward(g, mask, ctx.factor), None, None
+
+
 class FeedForward(nn.Module):
     """Pre-norm position-wise FFN with a half-step residual (model_conformer.py:10-29)."""
 
@@ -36,7 +54,13 @@ class FeedForward(nn.Module):
 
     def forward(self, x):
         y = self.dropout(self.swish(self.linear1(layer_norm_of(self.norm, x))))
-        return x + 0.5 * self.dropout(self.linear2(y))
+        z = self.linear2(y)
+        if x.is_cuda and z.dtype == x.dtype:
+            if self.training and torch.is_grad_enabled() and 0.0 < self.dropout.p < 1.0:
+                return _HalfStepResidual.apply(x, z, self.dropout.p, 0.5)
+            if not self.training or self.dropout.p == 0.0:
+                return torch.add(x, z, alpha=0.5)
+        return x + 0.5 * self.dropout(z)
 
 
 class MultiHeadSelfAttention(nn.Module):
