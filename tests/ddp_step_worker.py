@@ -26,12 +26,14 @@ ITERS = 16
 
 def main():
     mode = sys.argv[1]
+    kind = sys.argv[2] if len(sys.argv) > 2 else "crnn"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     device = torch.device("cuda", 0)
     import trainer
     cfg = trainer.config
-    cfg.MODEL_TYPE, cfg.CRNN_CNN_CHANNELS = "crnn", [16, 16, 32, 32]
+    cfg.MODEL_TYPE, cfg.CRNN_CNN_CHANNELS = kind, [16, 16, 32, 32]
+    cfg.RESNET_CONF_N_LAYERS = 1                  # (a one-block Conformer stack behind the ResNet-50 encoder keeps the run short)
     cfg.GRAPH_STEP = mode != "ddp"
     cfg.OVERLAP_ALLREDUCE = mode != "blocking"
     cfg.GRAD_REDUCE_DTYPE = "fp32" if mode == "fp32wire" else "param"
@@ -44,6 +46,8 @@ def main():
             m.p = 0.0
         if isinstance(m, torch.nn.GRU):
             m.dropout = 0.0
+        if hasattr(m, "dropout") and isinstance(getattr(m, "dropout"), torch.nn.Dropout):
+            m.dropout.p = 0.0
     trainer.enable_master_weights(model, device)
     graphed = trainer.graph_step_enabled(device, world)
     assert graphed == (mode != "ddp")
@@ -53,9 +57,10 @@ def main():
     step = trainer.make_stepper(model, crit, opt, device, world)
     g = torch.Generator().manual_seed(7 + rank)   # per-rank batches
     losses = []
+    batch = 4 if kind == "crnn" else 2
     for i in range(ITERS):
-        x = (torch.randn(4, 250, 4, 64, generator=g) * 20 - 30).to(device)
-        m = ((torch.rand(4, 250, 648, generator=g) < 0.02).to(torch.int32) << 3).to(torch.uint16).to(device)
+        x = (torch.randn(batch, 250, 4, 64, generator=g) * 20 - 30).to(device)
+        m = ((torch.rand(batch, 250, 648, generator=g) < 0.02).to(torch.int32) << 3).to(torch.uint16).to(device)
         total, _ = step(x, m)
         losses.append(float(total.item()))
     stats = step.stats() if hasattr(step, "stats") else None

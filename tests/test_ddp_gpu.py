@@ -78,18 +78,18 @@ def test_train_model_shards_the_device_feed(gpu_device, tmp_path):
 _runs = {}
 
 
-def _exchange_run(mode, port_base):
-    """One two-rank run of tests/ddp_step_worker.py per mode and test session (the runs are deterministic)."""
-    if mode not in _runs:
-        _runs[mode] = _exchange_run_uncached(mode, port_base)
-    return _runs[mode]
+def _exchange_run(mode, port_base, kind="crnn"):
+    """One two-rank run of tests/ddp_step_worker.py per mode, model and test session (the runs are deterministic)."""
+    if (mode, kind) not in _runs:
+        _runs[(mode, kind)] = _exchange_run_uncached(mode, port_base, kind)
+    return _runs[(mode, kind)]
 
 
-def _exchange_run_uncached(mode, port_base):
+def _exchange_run_uncached(mode, port_base, kind="crnn"):
     env = dict(os.environ, SELD_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     port = port_base + os.getpid() % 90
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(ROOT / "tests" / "ddp_step_worker.py"), mode]
+           "--master-port", str(port), str(ROOT / "tests" / "ddp_step_worker.py"), mode, kind]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
     assert out.returncode == 0, out.stderr[-3000:]
     lines = sorted((json.loads(l.split("RANKLINE ", 1)[1]) for l in out.stdout.splitlines() if "RANKLINE " in l),
@@ -198,3 +198,20 @@ def test_bf16_gradient_sum_error_of_eight_ranks(gpu_device):
         print(f"  {name:34s} {a:.2e} {b:.1e} {c:.2e}")
     print(f"  whole buffer {whole:.2e}, worst tensor {worst:.2e}")
     assert worst <= 6e-3 and whole <= 4e-3, (worst, whole)
+
+
+@pytest.mark.parametrize("kind", ["conformer", "resnet_conformer"])
+def test_overlapped_exchange_of_the_other_models(gpu_device, kind):
+    """The cut points of the Conformer (shared encoder) and of the ResNet50-Conformer (after the encoder, before layer4)
+    under two ranks: replicas stay in sync, three gradient buckets travel, and the loss curve follows the blocking
+    exchange's (their attention backward adds with atomics: run-to-run differences in the last bits, so not bit for bit)."""
+    staged = _exchange_run("staged", 31100 if kind == "conformer" else 31300, kind)
+    blocking = _exchange_run("blocking", 31500 if kind == "conformer" else 31700, kind)
+    for lines in (staged, blocking):
+        assert lines[0]["digest"] == lines[1]["digest"]
+        assert all(0 < v < 1.5 for d in lines for v in d["losses"])
+    st = staged[0]["stats"]
+    assert st["capture_error"] is None and st["allreduce_overlap"] is True and st["backward_stages"] == 3
+    assert all(b["bytes"] > 0 for b in st["gradient_buckets"])
+    for a, b in zip(staged, blocking):
+        assert all(abs(x - y) <= 2e-2 * abs(x) for x, y in zip(a["losses"], b["losses"])), (a["losses"], b["losses"])
