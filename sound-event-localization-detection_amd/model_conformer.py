@@ -192,7 +192,7 @@ class SELD_Conformer(nn.Module):
         if x.is_cuda:
             from model_crnn import run_cnn_blocks
             from seld_linear import linear_on_channels_last_features
-            enc = run_cnn_blocks(self.cnn_blocks, x)                       # [B, C, T, F], channels-last memory
+            enc = run_cnn_blocks(self.cnn_blocks, x, inner_cut=False)      # [B, C, T, F], channels-last memory
             y = linear_on_channels_last_features(self.proj, enc)           # no feature copy: the weight's columns move
             if y is None:
                 enc = enc.permute(0, 2, 1, 3)

@@ -117,8 +117,10 @@ def build_cnn_encoder(n_channels, n_mels, cnn_channels, max_pools=4):
     return blocks, channels, freq
 
 
-def run_cnn_blocks(blocks, x):
-    """[B, T, C, F] -> [B, C_out, T, F_out] (channels-last memory on a GPU)."""
+def run_cnn_blocks(blocks, x, inner_cut=True):
+    """[B, T, C, F] -> [B, C_out, T, F_out] (channels-last memory on a GPU).  ``inner_cut``: also mark the backward-pass
+    cut before the last block (worth a stage only when something is handed over to it: the CRNN's GRU layer 0 weight
+    gradients; for the Conformer that stage would complete no gradient bucket of its own)."""
     x = x.permute(0, 2, 1, 3)
     if x.is_cuda:
         # one copy does the layout change AND the cast the first convolution would otherwise do under autocast
@@ -132,7 +134,7 @@ def run_cnn_blocks(blocks, x):
                 # backward-pass cut points of the data-parallel captured step (identity otherwise): before the last
                 # block -- GRU layer 0's weight gradients, carried over from the recurrent stage, are computed beside
                 # that block's data gradient and travel under the rest -- and at the encoder's output
-                if depth == len(blocks) - 2:
+                if inner_cut and depth == len(blocks) - 2:
                     x = seld_cut.boundary(x, level=2)
         return seld_cut.boundary(x, level=1)
     for block in blocks:

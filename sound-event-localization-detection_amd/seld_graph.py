@@ -8,8 +8,8 @@ path takes its stream from the caller and nothing synchronises with the host, so
 input shape and replayed: the host then enqueues two window gathers and one graph launch per iteration.
 
 Data parallel (world > 1): the gradient all-reduce is OVERLAPPED WITH THE BACKWARD PASS.  The models mark cut points
-(``seld_cut.boundary``: the CRNN / Conformer between the recurrent / attention part and the convolution stack and before
-the last convolution block; the ResNet50-Conformer after its encoder and before ``layer4``), the backward pass is
+(``seld_cut.boundary``: the CRNN / Conformer between the recurrent / attention part and the convolution stack, the CRNN
+also before the last convolution block; the ResNet50-Conformer after its encoder and before ``layer4``), the backward pass is
 captured as one graph per STAGE, and the gradients that are final at the end of a stage travel while the next stages run:
 
     graph A0   forward + loss + backward down to the last cut   -> bucket 0 gathered into its flat buffer

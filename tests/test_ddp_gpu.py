@@ -203,7 +203,7 @@ def test_bf16_gradient_sum_error_of_eight_ranks(gpu_device):
 @pytest.mark.parametrize("kind", ["conformer", "resnet_conformer"])
 def test_overlapped_exchange_of_the_other_models(gpu_device, kind):
     """The cut points of the Conformer (shared encoder) and of the ResNet50-Conformer (after the encoder, before layer4)
-    under two ranks: replicas stay in sync, three gradient buckets travel, and the loss curve follows the blocking
+    under two ranks: replicas stay in sync, two / three gradient buckets travel, and the loss curve follows the blocking
     exchange's (their attention backward adds with atomics: run-to-run differences in the last bits, so not bit for bit)."""
     staged = _exchange_run("staged", 31100 if kind == "conformer" else 31300, kind)
     blocking = _exchange_run("blocking", 31500 if kind == "conformer" else 31700, kind)
@@ -211,7 +211,8 @@ def test_overlapped_exchange_of_the_other_models(gpu_device, kind):
         assert lines[0]["digest"] == lines[1]["digest"]
         assert all(0 < v < 1.5 for d in lines for v in d["losses"])
     st = staged[0]["stats"]
-    assert st["capture_error"] is None and st["allreduce_overlap"] is True and st["backward_stages"] == 3
+    assert st["capture_error"] is None and st["allreduce_overlap"] is True
+    assert st["backward_stages"] == (2 if kind == "conformer" else 3)
     assert all(b["bytes"] > 0 for b in st["gradient_buckets"])
     for a, b in zip(staged, blocking):
         assert all(abs(x - y) <= 2e-2 * abs(x) for x, y in zip(a["losses"], b["losses"])), (a["losses"], b["losses"])

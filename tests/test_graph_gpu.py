@@ -145,9 +145,9 @@ def test_other_models_staged_capture(gpu_device, kind):
     batches = _batches(gpu_device, 8, 2)
     one, _, _ = _train(kind, gpu_device, True, batches)
     cut, _, stats = _train(kind, gpu_device, True, batches, split=True)
-    assert stats["capture_error"] is None and stats["backward_stages"] == 3
+    assert stats["capture_error"] is None and stats["backward_stages"] == (2 if kind == "conformer" else 3)
     sizes = [b["bytes"] for b in stats["gradient_buckets"]]
-    assert sizes[0] > 0 and sizes[2] > 0
+    assert all(n > 0 for n in sizes)
     assert torch.isfinite(cut).all()
     assert (one - cut).abs().max().item() <= 2e-2 * one.abs().max().item()
 
