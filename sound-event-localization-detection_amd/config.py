@@ -113,7 +113,8 @@ class Config:
                                 # framework's fused Adam + cast
     GRAPH_STEP = True           # one optimiser iteration = one replayed HIP graph per input shape (seld_graph.py): the eager
                                 # loop spends ~3.5 ms of host time enqueueing ~300 launches per CRNN iteration; data
-                                # parallel: graph (forward + backward) -> flat all-reduce -> graph (Adam)
+                                # parallel: one graph per backward stage, gradient buckets all-reduced in between
+                                # (OVERLAP_ALLREDUCE below), then the update graph
     OVERLAP_ALLREDUCE = True    # data parallel + GRAPH_STEP: the backward pass is cut at the models' seld_cut.boundary points and
                                 # captured as one graph per stage; the gradients a stage completes are all-reduced (RCCL,
                                 # asynchronously) while the next stages run.  False: one graph, then one blocking exchange

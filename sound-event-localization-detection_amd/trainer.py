@@ -605,7 +605,7 @@ def train_model(train_loader, test_loader, num_epochs=None, batch_size=None, lea
     n_params = sum(p.numel() for p in model.parameters())
     enable_master_weights(model, device)
     graphed = graph_step_enabled(device, world)
-    # captured iterations exchange gradients themselves (one flat all-reduce between two graph replays); the eager
+    # captured iterations exchange gradients themselves (bucketed all-reduce between the stage graphs, seld_graph.py); the eager
     # path keeps DistributedDataParallel's bucketed, overlapped reducer
     model = broadcast_replica_state(model, world) if graphed else wrap_ddp(model, device, world)
 
