@@ -242,6 +242,9 @@ class GraphedTrainStep:
             total, term = self.criterion.loss_tensor(predictions, labels)
             self._out = (total.detach(), term.detach())
             root, grad = total, None
+            if total.is_cuda and total.dim() == 0 and total.dtype == torch.float32:
+                import seld_native
+                grad = seld_native.unit_gradient(total.device)     # no fill kernel, and the fused loss skips its x 1
         else:
             outer, leaf = self._cuts[len(self._cuts) - k]
             root, grad = outer, leaf.grad

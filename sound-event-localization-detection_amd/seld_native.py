@@ -442,9 +442,27 @@ def smr_loss(logits: torch.Tensor, labels: torch.Tensor, grid, w_class: float, w
     return out, grad
 
 
+_unit_gradients = {}        # device index -> a persistent ones scalar handed to autograd as the loss's upstream gradient
+
+
+def unit_gradient(device) -> torch.Tensor:
+    """The ones scalar ``loss.backward()`` would create with a fill kernel, kept per device: a caller that seeds the
+    backward pass with it (``torch.autograd.backward(loss, unit_gradient(device))``) saves that launch, and
+    ``scale_by_device_scalar_`` recognises it by address and skips its own (the upstream gradient IS one)."""
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    t = _unit_gradients.get(index)
+    if t is None:
+        t = _unit_gradients[index] = torch.ones((), dtype=torch.float32, device=device)
+    return t
+
+
 def scale_by_device_scalar_(data: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
     """data *= scale (a one-element fp32 GPU tensor) in place, without reading the scalar on the host; a scale of
     exactly 1.0 costs one empty launch.  Falls back to torch when the layout does not fit the kernel."""
+    if scale.is_cuda and scale.numel() == 1:
+        unit = _unit_gradients.get(scale.device.index)
+        if unit is not None and scale.data_ptr() == unit.data_ptr():
+            return data
     if (not data.is_cuda or data.dtype not in (torch.float32, torch.bfloat16) or not data.is_contiguous()
             or data.numel() % 8 or data.data_ptr() % 16 or scale.numel() != 1):
         return data.mul_(scale.to(data.dtype))
