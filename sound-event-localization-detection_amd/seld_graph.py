@@ -442,6 +442,8 @@ class GraphedTrainStep:
 
     def close(self):
         """Drop the graphs and hand the parameters ordinary (absent) gradients again."""
+        if self.device.type == "cuda" and self.shapes:
+            torch.cuda.synchronize(self.device)      # nothing of a replay is in flight when its graph is destroyed
         self.shapes.clear()
         self._cuts = []
         for p in self.params:
