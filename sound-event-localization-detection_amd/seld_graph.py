@@ -46,6 +46,7 @@ import seld_cut
 logger = logging.getLogger("SMR_SELD")
 
 WARMUP = 3
+_retired = []        # the graphs of the last two closed steppers (see GraphedTrainStep.close)
 
 
 def _unwrap(model):
@@ -443,7 +444,13 @@ class GraphedTrainStep:
     def close(self):
         """Drop the graphs and hand the parameters ordinary (absent) gradients again."""
         if self.device.type == "cuda" and self.shapes:
-            torch.cuda.synchronize(self.device)      # nothing of a replay is in flight when its graph is destroyed
+            # Nothing of a replay may be in flight when its graph is destroyed -- and the HIP runtime releases a finished
+            # launch's host-side command memory on its own callback thread a little AFTER the device reports idle (two
+            # test processes of round 3 aborted inside that thread's free() right after a stepper had been closed, DESIGN.md
+            # section 9): the graphs are parked and destroyed when the NEXT stepper closes, long after their last replay.
+            torch.cuda.synchronize(self.device)
+            _retired.append(dict(self.shapes))
+            del _retired[:-2]
         self.shapes.clear()
         self._cuts = []
         for p in self.params:
