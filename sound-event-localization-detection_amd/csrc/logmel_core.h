@@ -271,13 +271,17 @@ constexpr int kPhasorPitch = 488;            // 481 bins + 7: rows stay 16-byte 
 
 SELD_HD unsigned phasor_q15(float re, float im, float power) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  const float rs = __frsqrt_rn(power);                 // v_rsq_f32: 1 ulp, far below the 3e-5 quantisation step
+  // v_rsq_f32 (1 ulp, far below the 3e-5 quantisation step), then ONE v_cvt_pknorm_i16_f32: both components clamped to
+  // [-1, 1], scaled by 32767 and rounded to nearest, packed (re | im << 16)
+  const float rs = power > kSilencePower ? __frsqrt_rn(power) : 0.0f;
+  typedef short short2_t __attribute__((ext_vector_type(2)));
+  const short2_t q = __builtin_amdgcn_cvt_pknorm_i16(re * rs, im * rs);
+  return __builtin_bit_cast(unsigned, q);
 #else
-  const float rs = 1.0f / sqrtf(power);
-#endif
-  const float inv = power > kSilencePower ? 32767.0f * rs : 0.0f;
+  const float inv = power > kSilencePower ? 32767.0f * (1.0f / sqrtf(power)) : 0.0f;
   const int qr = static_cast<int>(rintf(re * inv)), qi = static_cast<int>(rintf(im * inv));
   return (static_cast<unsigned>(qr) & 0xffffu) | (static_cast<unsigned>(qi) << 16);
+#endif
 }
 
 // ``base`` is wavefront-uniform (a scalar register pair), ``off_a`` this lane's 32-bit word offset of bin l of frame a
