@@ -406,6 +406,27 @@ __device__ __forceinline__ void gm_fragments(const GmPhasors& x, half8& a_re, ha
   a_im = __builtin_shufflevector(i0, i1, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// cc[+l] = (C[l] + S[l]) / 960 at index 32 + l (l = 0..31),  cc[-l] = (C[l] - S[l]) / 960 at index 32 - l (l = 1..32);
+// the lag stride of the output is 1 (the host checks): 16-byte stores, the second set at a 4-byte aligned address.
+// `scale` = 1 / 960 times whatever factor the caller left out of its phase factors.
+__device__ __forceinline__ void gm_store_pairs(const GccMfmaArgs& a, const f32x4 (&acc_c)[kGmLagTiles],
+                                               const f32x4 (&acc_s)[kGmLagTiles], int pair, int g, int n_pairs, long n,
+                                               long t, float scale = 1.0f / 960.0f) {
+  if (pair >= n_pairs) return;
+  float* op = a.out + n * a.sN + pair * a.sC + t * a.sT;
+#pragma unroll
+  for (int tl = 0; tl < 2; ++tl) {
+    const int l0 = 16 * tl + 4 * g;
+    const f32x4 plus = (acc_c[tl] + acc_s[tl]) * scale;
+    const f32x4 minus = (acc_c[tl] - acc_s[tl]) * scale;           // at l0 = 0 its first value is cc[0] again (S[0] = 0)
+    *reinterpret_cast<f32x4*>(op + 32 + l0) = plus;
+    struct __attribute__((packed, aligned(4))) Unaligned4 { float v[4]; };
+    Unaligned4 rev = {{minus[3], minus[2], minus[1], minus[0]}};
+    *reinterpret_cast<Unaligned4*>(op + 29 - l0) = rev;
+  }
+  if (g == 0) op[0] = (acc_c[2][0] - acc_s[2][0]) * scale;         // lag -32
+}
+
 template <bool kHasZero>
 __device__ __forceinline__ void gcc_mfma_frame(const GccMfmaArgs& a, const float* u, const half8* table, int lane, int mt,
                                                int n_pairs, long n, long t) {
@@ -467,24 +488,7 @@ __device__ __forceinline__ void gcc_mfma_frame(const GccMfmaArgs& a, const float
     cur = nxt;
     tcur = tnxt;
   }
-  // cc[+l] = (C[l] + S[l]) / 960 at index 32 + l (l = 0..31),  cc[-l] = (C[l] - S[l]) / 960 at index 32 - l (l = 1..32);
-  // the lag stride of the output is 1 (the host checks): 16-byte stores, the second set at a 4-byte aligned address.
-  const float sc = 1.0f / 960.0f;
-  const int pair = 16 * mt + r;
-  if (pair < n_pairs) {
-    float* op = a.out + n * a.sN + pair * a.sC + t * a.sT;
-#pragma unroll
-    for (int tl = 0; tl < 2; ++tl) {
-      const int l0 = 16 * tl + 4 * g;
-      const f32x4 plus = (acc_c[tl] + acc_s[tl]) * sc;
-      const f32x4 minus = (acc_c[tl] - acc_s[tl]) * sc;            // at l0 = 0 its first value is cc[0] again (S[0] = 0)
-      *reinterpret_cast<f32x4*>(op + 32 + l0) = plus;
-      struct __attribute__((packed, aligned(4))) Unaligned4 { float v[4]; };
-      Unaligned4 rev = {{minus[3], minus[2], minus[1], minus[0]}};
-      *reinterpret_cast<Unaligned4*>(op + 29 - l0) = rev;
-    }
-    if (g == 0) op[0] = (acc_c[2][0] - acc_s[2][0]) * sc;          // lag -32
-  }
+  gm_store_pairs(a, acc_c, acc_s, 16 * mt + r, g, n_pairs, n, t);
 }
 
 // Workgroup barrier for data exchanged through LDS: wait for this wavefront's LDS operations, then s_barrier -- what hipcc
@@ -619,6 +623,267 @@ __global__ __launch_bounds__(kGmThreads, 1) void gcc_mfma_kernel(GccMfmaArgs a) 
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The Q15 kernel proper: the same matrix-core transform, fed with the phasor WORDS as they lie in HBM.
+//
+// gcc_mfma_kernel<true> above unpacks every word to two floats in LDS (31 KB per frame, so two frames per workgroup, two
+// wavefronts per frame) and forms conj(Um) Un in fp32; its products phase is bound by what the wavefronts read from LDS
+// (14 KB per 32-bin step).  Here the words stay packed:
+//   * LDS holds a frame as 8 channel rows of 488 words (15.6 KB): FOUR frames fit beside the 96 KB table, one per
+//     wavefront, each wavefront doing both pair tiles of its frame -- so a table fragment read from LDS feeds two MFMAs
+//     and a 32-bin step reads 14 KB for twelve MFMAs instead of six;
+//   * staging is a copy (global b128 -> registers -> ds_write_b128), and because a frame belongs to ONE wavefront the
+//     loop has no workgroup barrier at all: LDS operations of a wavefront complete in order;
+//   * conj(Um) Un of two Q15 words is two integer dot products, EXACT in int32: Re = (mr, mi) . (nr, ni),
+//     Im = (mr, mi) . (ni, -nr) (v_dot2_i32_i16; the second operand is the first rotated by 16 bits with its upper half
+//     negated); int32 -> fp32 -> one rounding to fp16, as before.  The 1 / 32767^2 of the Q15 scale is folded into the
+//     conversion to keep the fp16 operand in [-1, 1].
+// LDS bank slots: a wavefront's ds_read_b128 is serviced in groups of 16 lanes that hold up to eight channels x two
+// neighbouring bin groups (8 bins = 32 B = two 16-byte units).  A channel row is 122 units, i.e. rows start at units
+// 10 c mod 16 = all eight EVEN residues; the two units of every ODD bin group are stored swapped (gq_unit_slot), which
+// puts the odd groups' first halves on the odd residues: 16 distinct slots, no conflicts, no padding.
+constexpr int kGqRowUnits = kPhasorPitch / 4;                     // 16-byte units per (channel, frame) row: 122
+constexpr int kGqRowBytes = kGqRowUnits * 16;
+constexpr int kGqFrameUnits = 8 * kGqRowUnits;                    // 976
+constexpr int kGqFrameBytes = kGqFrameUnits * 16;                 // 15 616
+constexpr int kGqUnitsPerLane = (kGqFrameUnits + 63) / 64;        // 16 (the last round: lanes 0..15)
+constexpr int kGqDumpBytes = 64 * 16;                              // where lanes with nothing to copy write (per wavefront: shared, never read)
+constexpr int kGqLdsBytes = kGmTableBytes + kGmWaves * kGqFrameBytes + kGqDumpBytes;   // 161 792 B
+static_assert(kGqLdsBytes <= 160 * 1024, "gcc_q15_kernel: table + four frames must fit the CU's LDS");
+static_assert(kPhasorPitch % 8 == 0 && kPhasorPitch >= 8 * 61, "gcc_q15_kernel: rows hold 61 whole bin groups");
+
+// where unit i of a row (bins 4 i .. 4 i + 3) is stored: the halves of odd bin groups (i >> 1) swapped
+__device__ __forceinline__ int gq_unit_slot(int i) { return (i & ~1) | ((i ^ (i >> 1)) & 1); }
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kQ15One = 32767 * 32767;                             // the integer product that stands for 1.0
+
+struct GqWords {               // 8 bins of the two channels of a pair, one Q15 word (re | im << 16) each
+  u32x4 m0, m1, n0, n1;
+};
+
+// v_dot2_i32_i16 with a zero addend.  The builtin (__builtin_amdgcn_sdot2) is selected as the two-operand v_dot2c, whose
+// accumulator IS the destination: a v_mov 0 per product, a quarter of the instructions of the fragment.  The
+// three-operand encoding is written out instead, the eight products of a fragment in ONE statement: the compiler cannot
+// see that an asm statement is a dot instruction, so the wait states this target wants between a dot instruction's write
+// and another vector instruction that reads (3) or overwrites (4) the register are supplied here -- within the
+// statement no product reads another's result, and the s_nop covers the last ones.
+__device__ __forceinline__ void gq_dots(const unsigned (&wm)[8], const unsigned (&wn)[8], int (&out)[8]) {
+  asm("v_dot2_i32_i16 %0, %8, %16, 0\n\tv_dot2_i32_i16 %1, %9, %17, 0\n\t"
+      "v_dot2_i32_i16 %2, %10, %18, 0\n\tv_dot2_i32_i16 %3, %11, %19, 0\n\t"
+      "v_dot2_i32_i16 %4, %12, %20, 0\n\tv_dot2_i32_i16 %5, %13, %21, 0\n\t"
+      "v_dot2_i32_i16 %6, %14, %22, 0\n\tv_dot2_i32_i16 %7, %15, %23, 0\n\t"
+      "s_nop 3"
+      : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]),
+        "=&v"(out[7])
+      : "v"(wm[0]), "v"(wm[1]), "v"(wm[2]), "v"(wm[3]), "v"(wm[4]), "v"(wm[5]), "v"(wm[6]), "v"(wm[7]),
+        "v"(wn[0]), "v"(wn[1]), "v"(wn[2]), "v"(wn[3]), "v"(wn[4]), "v"(wn[5]), "v"(wn[6]), "v"(wn[7]));
+}
+
+template <bool kHasZero>
+__device__ __forceinline__ void gq_fragments(const GqWords& x, half8& b_re, half8& b_im) {
+  unsigned wm[8], wn[8], wq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    wm[j] = j < 4 ? x.m0[j & 3] : x.m1[j & 3];
+    wn[j] = j < 4 ? x.n0[j & 3] : x.n1[j & 3];
+    // (ni, -nr) = (hi * 1, lo * 0xffff) mod 2^16: one packed multiply whose op_sel swaps the halves of wn (|nr| <= 32767:
+    // the negation cannot overflow)
+    asm("v_pk_mul_lo_u16 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(wq[j]) : "v"(wn[j]), "s"(0xffff0001u));
+  }
+  int ri[8], ii[8];
+  gq_dots(wm, wn, ri);                                              // Re = (mr, mi) . (nr, ni)
+  gq_dots(wm, wq, ii);                                              // Im = (mr, mi) . (ni, -nr)
+  f32x4 re[2], im[2];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int r = ri[j], i = ii[j];
+    if (kHasZero) {                                                 // a silent channel's word is 0: factor 1
+      const bool z = wm[j] == 0u || wn[j] == 0u;
+      r = z ? kQ15One : r;
+      i = z ? 0 : i;
+    }
+    re[j >> 2][j & 3] = static_cast<float>(r);
+    im[j >> 2][j & 3] = static_cast<float>(i);
+  }
+  const float s = 1.0f / (32767.0f * 32767.0f);
+  const half4 r0 = __builtin_convertvector(re[0] * s, half4), r1 = __builtin_convertvector(re[1] * s, half4);
+  const half4 i0 = __builtin_convertvector(im[0] * s, half4), i1 = __builtin_convertvector(im[1] * s, half4);
+  b_re = __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7);
+  b_im = __builtin_shufflevector(i0, i1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// One frame (both pair tiles when kTiles == 2) by one wavefront; `u` = the wavefront's frame in LDS; om / on = byte offsets
+// of the rows of the lane's pairs' channels (gq_pair_rows: loop invariant, and pair_channels reads a table from global
+// memory -- inside the frame loop its vmcnt(0) would also wait for the next frame's requests).
+template <bool kHasZero, int kTiles>
+__device__ __forceinline__ void gcc_q15_frame(const unsigned char* u, const half8* table, int lane, const int (&om)[2],
+                                              const int (&on)[2], f32x4 (&acc_c)[kTiles][kGmLagTiles],
+                                              f32x4 (&acc_s)[kTiles][kGmLagTiles]) {
+  const int g = lane >> 4;
+  // the lane's two units (bins 0..3 | 4..7 of bin group 4 ks + g) within a row; step ks adds 128 bytes.  The last step
+  // reads bin group 60 for every lane (groups 61..63 do not exist; their table rows are zero).
+  const int lo = (2 * g + (g & 1)) * 16, hi = (2 * g + 1 - (g & 1)) * 16;
+  const half8* tab = table + lane;
+#pragma unroll
+  for (int tile = 0; tile < kTiles; ++tile)
+#pragma unroll
+    for (int tl = 0; tl < kGmLagTiles; ++tl)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc_c[tile][tl][i] = acc_s[tile][tl][i] = 0.0f;
+  struct TableFrags { half8 c[kGmLagTiles], s[kGmLagTiles]; };
+  auto table_load = [&](int ks, TableFrags& tf) {
+#pragma unroll
+    for (int tl = 0; tl < kGmLagTiles; ++tl) {
+      tf.c[tl] = tab[((0 * kGmLagTiles + tl) * kGmKSteps + ks) * 64];
+      tf.s[tl] = tab[((1 * kGmLagTiles + tl) * kGmKSteps + ks) * 64];
+    }
+  };
+  auto words_load = [&](int ks, int tile, GqWords& w) {
+    const bool last = ks == kGmKSteps - 1;                         // compile-time per unrolled step
+    const int l = last ? 120 * 16 : lo + 128 * ks, h = last ? 121 * 16 : hi + 128 * ks;
+    w.m0 = *reinterpret_cast<const u32x4*>(u + om[tile] + l);
+    w.m1 = *reinterpret_cast<const u32x4*>(u + om[tile] + h);
+    w.n0 = *reinterpret_cast<const u32x4*>(u + on[tile] + l);
+    w.n1 = *reinterpret_cast<const u32x4*>(u + on[tile] + h);
+  };
+  // A step: the phase factors of both tiles (vector units), then the twelve products.  Single buffers: the next step's
+  // words are requested once the fragments are formed (they arrive under the products), the next step's table
+  // fragments once the products are issued (they arrive under the next step's vector work).  Requesting everything a
+  // whole step ahead instead needs 70 more registers, and with those the compiler parked the NEXT FRAME's requests in
+  // accumulator registers -- waiting for them at the start of the frame.
+  GqWords w[kTiles];
+  TableFrags tf;
+#pragma unroll
+  for (int tile = 0; tile < kTiles; ++tile) words_load(0, tile, w[tile]);
+  table_load(0, tf);
+#pragma unroll
+  for (int ks = 0; ks < kGmKSteps; ++ks) {                   // fully unrolled: every LDS offset is an immediate
+    half8 b_re[kTiles], b_im[kTiles];
+#pragma unroll
+    for (int tile = 0; tile < kTiles; ++tile) gq_fragments<kHasZero>(w[tile], b_re[tile], b_im[tile]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 1 < kGmKSteps) {
+#pragma unroll
+      for (int tile = 0; tile < kTiles; ++tile) words_load(ks + 1, tile, w[tile]);
+    }
+    __builtin_amdgcn_sched_barrier(0);                       // (left alone the scheduler sinks the reads to their use)
+#pragma unroll
+    for (int tile = 0; tile < kTiles; ++tile) {
+#pragma unroll
+      for (int tl = 0; tl < kGmLagTiles; ++tl) {
+        acc_c[tile][tl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tf.c[tl], b_re[tile], acc_c[tile][tl], 0, 0, 0);
+        acc_s[tile][tl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tf.s[tl], b_im[tile], acc_s[tile][tl], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 1 < kGmKSteps) table_load(ks + 1, tf);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int kTiles>
+__global__ __launch_bounds__(kGmThreads, 1) void gcc_q15_kernel(GccMfmaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const half8* table = reinterpret_cast<const half8*>(smem_raw);
+  unsigned char* u = smem_raw + kGmTableBytes + wave * kGqFrameBytes;      // this wavefront's frame
+  {                                                                // the constant table, once per workgroup
+    const uint4* src = static_cast<const uint4*>(a.table);
+    uint4* dst = reinterpret_cast<uint4*>(smem_raw);
+    for (int i = tid; i < kGmTableBytes / 16; i += kGmThreads) dst[i] = src[i];
+  }
+  const int n_pairs = static_cast<int>(a.C * (a.C - 1) / 2);
+  const int n_ch = static_cast<int>(a.C);
+  const long total = a.N * a.F;
+  // Lane `lane` copies units lane + 64 i of the frame (unit = 16 bytes = 4 bins; row c = units 122 c ..): where from and
+  // where to is loop invariant.  Rows of channels the clip does not have are never read by a pair.  Words 481..487 of a
+  // row are whatever the log-mel pass left there (it never writes them): they meet zero table rows, and an integer
+  // product is finite whatever the words are.
+  const uint4* spec = reinterpret_cast<const uint4*>(a.spec);
+  const unsigned ch_stride = static_cast<unsigned>(a.F) * kGqRowUnits;     // units; the host checks C F 488 < 2^31
+  // Every lane loads and stores in every round -- a lane with nothing to copy reads unit 0 and writes to a dump slot
+  // past the frames: a load or a copy under a lane mask leaves the compiler unable to tell whether the request is still
+  // outstanding, and it then waits for ALL memory operations (vmcnt(0), the output stores included) wherever it reuses
+  // the register.
+  unsigned src_off[kGqUnitsPerLane];
+  int dst_off[kGqUnitsPerLane];
+  unsigned all_mask = 0, first_mask = 0;                           // per round: all four words are bins | only the first is
+  const int dump_off = kGmWaves * kGqFrameBytes - wave * kGqFrameBytes + lane * 16;    // relative to u
+#pragma unroll
+  for (int i = 0; i < kGqUnitsPerLane; ++i) {
+    const int unit = lane + 64 * i;
+    const int c = unit / kGqRowUnits, ir = unit - c * kGqRowUnits;
+    const bool valid = unit < kGqFrameUnits && c < n_ch;
+    src_off[i] = valid ? static_cast<unsigned>(c) * ch_stride + static_cast<unsigned>(ir) : 0u;
+    dst_off[i] = valid ? c * kGqRowBytes + gq_unit_slot(ir) * 16 : dump_off;
+    all_mask |= valid && ir < (kBins - 1) / 4 ? 1u << i : 0u;      // units 0..119: bins 0..479
+    first_mask |= valid && ir == (kBins - 1) / 4 ? 1u << i : 0u;   // unit 120: bin 480 and three words past the row
+  }
+  auto frame_base = [&](long f) {
+    const long n = f / a.F;
+    return spec + (n * a.C * a.F + (f - n * a.F)) * kGqRowUnits;
+  };
+  int om[2] = {0, 0}, on[2] = {0, 0};                              // rows of the channels of the lane's pair, per tile
+#pragma unroll
+  for (int tile = 0; tile < kTiles; ++tile) {
+    int p = 16 * tile + (lane & 15);
+    if (p >= n_pairs) p = n_pairs - 1;                             // rows past the last pair repeat it (never stored)
+    int cm, cn;
+    pair_channels(p, n_ch, cm, cn);
+    om[tile] = cm * kGqRowBytes;
+    on[tile] = cn * kGqRowBytes;
+  }
+  uint4 pre[kGqUnitsPerLane];
+  auto request = [&](const uint4* src) {
+#pragma unroll
+    for (int i = 0; i < kGqUnitsPerLane; ++i) pre[i] = src[src_off[i]];
+  };
+  auto stage = [&]() {                                             // requested words -> LDS; true if a bin of the frame is silent
+    bool zero = false;
+#pragma unroll
+    for (int i = 0; i < kGqUnitsPerLane; ++i) {
+      const uint4 w = pre[i];
+      *reinterpret_cast<uint4*>(u + dst_off[i]) = w;
+      const bool z_first = w.x == 0u;
+      const bool z_all = z_first | (w.y == 0u) | (w.z == 0u) | (w.w == 0u);
+      zero |= ((all_mask >> i & 1) != 0 & z_all) | ((first_mask >> i & 1) != 0 & z_first);
+    }
+    return __builtin_amdgcn_ballot_w64(zero) != 0;
+  };
+  const long stride = static_cast<long>(kGmWaves) * gridDim.x;
+  long f = static_cast<long>(kGmWaves) * blockIdx.x + wave;
+  if (f < total) request(frame_base(f));
+  __syncthreads();                                                 // the table is in place; no barrier after this one
+  bool has_zero = false;
+  if (f < total) {
+    has_zero = stage();
+    __builtin_amdgcn_sched_barrier(0);
+    if (f + stride < total) request(frame_base(f + stride));
+  }
+  // Order within an iteration: products of frame f | next frame's words -> LDS | frame f's stores | requests for the frame
+  // after next.  (Stores and loads share the vmcnt counter, which retires in order: with the stores issued BEFORE the
+  // copy, the copy's wait for the requests would also wait for the stores' acknowledgements, issued moments earlier.)
+  for (; f < total; f += stride) {                                 // trip count per WAVEFRONT
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the frame is in LDS (same wavefront: no barrier)
+    const long n = f / a.F;
+    const long t = f - n * a.F;
+    f32x4 acc_c[kTiles][kGmLagTiles], acc_s[kTiles][kGmLagTiles];
+    if (has_zero) gcc_q15_frame<true, kTiles>(u, table, lane, om, on, acc_c, acc_s);
+    else gcc_q15_frame<false, kTiles>(u, table, lane, om, on, acc_c, acc_s);
+    if (f + stride < total) has_zero = stage();
+#pragma unroll
+    for (int tile = 0; tile < kTiles; ++tile)
+      gm_store_pairs(a, acc_c[tile], acc_s[tile], 16 * tile + (lane & 15), lane >> 4, n_pairs, n, t);
+    __builtin_amdgcn_sched_barrier(0);
+    if (f + 2 * stride < total) request(frame_base(f + 2 * stride));       // in flight across the next frame's products
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // fp32 -> IEEE binary16 bits, round to nearest even (host side of the table build; |v| <= 2, no overflow handling needed)
 static unsigned short half_bits(float v) {
   unsigned u;
@@ -685,15 +950,35 @@ static int launch_gcc_q15(seld::DeviceState* st, const uint32_t* phasors, int64_
                           int64_t sN, int64_t sC, int64_t sM, int64_t sT, void* stream_) {
   using namespace seld;
   GccMfmaArgs a{reinterpret_cast<const float*>(phasors), out, N, C, F, sN, sC, sM, sT, st->gcc_table};
-  long blocks = (N * F + 1) / 2;
-  if (blocks > st->num_cus) blocks = st->num_cus;           // persistent: the 96 KB table is staged once per workgroup
   if (need_lds(st, kAttrGccMfmaQ15)) {
     SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gcc_mfma_kernel<true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, kGmLdsBytes));
+    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gcc_q15_kernel<1>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kGqLdsBytes));
+    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gcc_q15_kernel<2>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kGqLdsBytes));
     lds_attr_set(st, kAttrGccMfmaQ15);
   }
-  hipLaunchKernelGGL(gcc_mfma_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(kGmThreads), kGmLdsBytes,
-                     static_cast<hipStream_t>(stream_), a);
+  // SELD_GCC=planar selects the kernel that unpacks the words to fp32 in LDS (the round-3a path): developer A/B, read per
+  // call because the tests run both kernels in one process
+  const char* which = getenv("SELD_GCC");
+  const bool planar = which && which[0] == 'p';
+  // persistent workgroups: the 96 KB table is staged once per workgroup
+  if (planar) {
+    long blocks = (N * F + 1) / 2;
+    if (blocks > st->num_cus) blocks = st->num_cus;
+    hipLaunchKernelGGL(gcc_mfma_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(kGmThreads), kGmLdsBytes,
+                       static_cast<hipStream_t>(stream_), a);
+  } else {
+    long blocks = (N * F + kGmWaves - 1) / kGmWaves;
+    if (blocks > st->num_cus) blocks = st->num_cus;
+    if (C * (C - 1) / 2 > 16)                                 // 7 or 8 channels: two tiles of 16 pairs
+      hipLaunchKernelGGL(gcc_q15_kernel<2>, dim3(static_cast<unsigned>(blocks)), dim3(kGmThreads), kGqLdsBytes,
+                         static_cast<hipStream_t>(stream_), a);
+    else
+      hipLaunchKernelGGL(gcc_q15_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(kGmThreads), kGqLdsBytes,
+                         static_cast<hipStream_t>(stream_), a);
+  }
   SELD_HIP_TRY(hipGetLastError());
   return kOk;
 }

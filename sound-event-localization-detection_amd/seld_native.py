@@ -1053,6 +1053,7 @@ def spatial_features(pcm: torch.Tensor, kind: str) -> torch.Tensor:
     import os
     mode = os.environ.get("SELD_GCC", "mfma")                # developer A/B: "fft" = the FFT kernel, "spectra" = the
     if kind == "logmel_gcc" and mode not in ("fft", "spectra"):     # matrix-core kernel fed with complex64 spectra
+        # ("planar" is read by the library: the Q15 kernel that unpacks the words to fp32 in LDS)
         # default: the log-mel pass also writes every bin's phasor X / |X| as Q15 pairs (4 B per bin instead of the 8 B of
         # the complex64 spectrum: half the HBM bytes on both sides) and the matrix-core GCC-PHAT kernel reads those
         pitch = int(lib.seld_phasor_pitch())

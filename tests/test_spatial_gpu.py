@@ -41,12 +41,14 @@ def test_foa_intensity_vectors(gpu_device):
     assert np.abs(ref[0]).max() > 0.1                                     # the planted correlation shows up
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "spectra", "fft"])
-@pytest.mark.parametrize("channels", [8, 4, 2])
+@pytest.mark.parametrize("kernel", ["mfma", "planar", "spectra", "fft"])
+@pytest.mark.parametrize("channels", [8, 7, 6, 4, 2])
 def test_gcc_phat(gpu_device, channels, kernel, monkeypatch):
-    """The GCC-PHAT paths (csrc/spatial.hip): the matrix-core kernel fed with the log-mel pass's Q15 phasors (default), the
-    same kernel fed with complex64 spectra (SELD_GCC=spectra: what seld_gcc_phat does on an exported STFT), and the
-    FFT-based one that serves outputs whose lag stride is not 1 (SELD_GCC=fft)."""
+    """The GCC-PHAT paths (csrc/spatial.hip): the matrix-core kernel fed with the log-mel pass's Q15 phasors, products by
+    integer dot products on the packed words (default); the one that unpacks the words to fp32 in LDS (SELD_GCC=planar);
+    the same fed with complex64 spectra (SELD_GCC=spectra: what seld_gcc_phat does on an exported STFT); and the FFT-based
+    one that serves outputs whose lag stride is not 1 (SELD_GCC=fft).  7 and 6 channels = 21 and 15 pairs: either side of
+    the 16-pair tile boundary."""
     import seld_native
     monkeypatch.setenv("SELD_GCC", kernel)
     pcm = ofeat.synth_pcm(6, channels, 12000 + 17, "noise")
@@ -74,7 +76,7 @@ def test_batched_spatial_features(gpu_device):
         assert torch.equal(gcc[i], seld_native.spatial_features(pcm[i], "logmel_gcc"))
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "spectra", "fft"])
+@pytest.mark.parametrize("kernel", ["mfma", "planar", "spectra", "fft"])
 def test_gcc_phat_with_a_silent_channel(gpu_device, kernel, monkeypatch):
     """X = 0 must give R / |R| = 1 (np.exp(1j * np.angle(0))): pairs with the dead microphone are a unit pulse at lag 0,
     the other pairs are untouched.  (The kernel stores a zero phasor for such a channel and switches, per frame, to the
