@@ -346,7 +346,7 @@ def kernel_rooflines(device):
         timeit(lambda: nat.logmel(pcm16, layout="tcf", out=lm_out), reps=5))
     del pcm16, lm_out
     pcm8 = torch.randn(clips, 8, CLIP_SAMPLES, device=device) * 0.1
-    hbm(f"spatial_features logmel_gcc ({clips} clips x 8 ch: logmel_main_kernel<float, 2> (Q15 phasors) + gcc_mfma_kernel<true>)",
+    hbm(f"spatial_features logmel_gcc ({clips} clips x 8 ch: logmel_main_kernel<float, 2> (Q15 phasors) + gcc_q15_kernel<2>)",
         clips * (8 * CLIP_SAMPLES * 4 + 36 * 64 * (1 + CLIP_SAMPLES // 480) * 4),
         timeit(lambda: nat.spatial_features(pcm8, "logmel_gcc"), reps=3))
     del pcm8
@@ -630,7 +630,7 @@ def main():
                        "final_loss": float(loss.item())},
             "roofline": {"kernel": "seld::logmel_main_kernel<float, false> (fused STFT+mel+dB; the edge iterations are its "
                                    "trailing workgroups)"
-                         if args.features == "logmel" else f"feature phase: {'seld::logmel_main_kernel<float, 2> (log-mel + Q15 phasors) + seld::gcc_mfma_kernel<true>' if args.features == 'logmel_gcc' else 'seld::logmel_main_kernel<float, 1> (log-mel + spectra) + seld::foa_iv_kernel'}",
+                         if args.features == "logmel" else f"feature phase: {'seld::logmel_main_kernel<float, 2> (log-mel + Q15 phasors) + seld::gcc_q15_kernel<2>' if args.features == 'logmel_gcc' else 'seld::logmel_main_kernel<float, 1> (log-mel + spectra) + seld::foa_iv_kernel'}",
                          "bound": "hbm",
                          "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS,

@@ -646,9 +646,10 @@ constexpr int kGqRowUnits = kPhasorPitch / 4;                     // 16-byte uni
 constexpr int kGqRowBytes = kGqRowUnits * 16;
 constexpr int kGqFrameUnits = 8 * kGqRowUnits;                    // 976
 constexpr int kGqFrameBytes = kGqFrameUnits * 16;                 // 15 616
-constexpr int kGqUnitsPerLane = (kGqFrameUnits + 63) / 64;        // 16 (the last round: lanes 0..15)
+constexpr int kGqUnitsPerLane = (kGqFrameUnits + 63) / 64;        // copy rounds of 64 units: 16 (the last: lanes 0..15)
 constexpr int kGqDumpBytes = 64 * 16;                              // where lanes with nothing to copy write (per wavefront: shared, never read)
-constexpr int kGqLdsBytes = kGmTableBytes + kGmWaves * kGqFrameBytes + kGqDumpBytes;   // 161 792 B
+constexpr int kGqFrames = 4;                                       // frames per workgroup
+constexpr int kGqLdsBytes = kGmTableBytes + kGqFrames * kGqFrameBytes + kGqDumpBytes + 2 * kGqFrames * 4;   // 161 824 B
 static_assert(kGqLdsBytes <= 160 * 1024, "gcc_q15_kernel: table + four frames must fit the CU's LDS");
 static_assert(kPhasorPitch % 8 == 0 && kPhasorPitch >= 8 * 61, "gcc_q15_kernel: rows hold 61 whole bin groups");
 
@@ -671,19 +672,26 @@ struct GqWords {               // 8 bins of the two channels of a pair, one Q15 
 // and another vector instruction that reads (3) or overwrites (4) the register are supplied here -- within the
 // statement no product reads another's result, and the s_nop covers the last ones.
 __device__ __forceinline__ void gq_dots(const unsigned (&wm)[8], const unsigned (&wn)[8], int (&out)[8]) {
-  asm("v_dot2_i32_i16 %0, %8, %16, 0\n\tv_dot2_i32_i16 %1, %9, %17, 0\n\t"
-      "v_dot2_i32_i16 %2, %10, %18, 0\n\tv_dot2_i32_i16 %3, %11, %19, 0\n\t"
-      "v_dot2_i32_i16 %4, %12, %20, 0\n\tv_dot2_i32_i16 %5, %13, %21, 0\n\t"
-      "v_dot2_i32_i16 %6, %14, %22, 0\n\tv_dot2_i32_i16 %7, %15, %23, 0\n\t"
+  asm("v_dot2_i32_i16 %0, %8, %16, %24\n\tv_dot2_i32_i16 %1, %9, %17, %24\n\t"
+      "v_dot2_i32_i16 %2, %10, %18, %24\n\tv_dot2_i32_i16 %3, %11, %19, %24\n\t"
+      "v_dot2_i32_i16 %4, %12, %20, %24\n\tv_dot2_i32_i16 %5, %13, %21, %24\n\t"
+      "v_dot2_i32_i16 %6, %14, %22, %24\n\tv_dot2_i32_i16 %7, %15, %23, %24\n\t"
       "s_nop 3"
       : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]),
         "=&v"(out[7])
       : "v"(wm[0]), "v"(wm[1]), "v"(wm[2]), "v"(wm[3]), "v"(wm[4]), "v"(wm[5]), "v"(wm[6]), "v"(wm[7]),
-        "v"(wn[0]), "v"(wn[1]), "v"(wn[2]), "v"(wn[3]), "v"(wn[4]), "v"(wn[5]), "v"(wn[6]), "v"(wn[7]));
+        "v"(wn[0]), "v"(wn[1]), "v"(wn[2]), "v"(wn[3]), "v"(wn[4]), "v"(wn[5]), "v"(wn[6]), "v"(wn[7]),
+        "s"(1 << 15));                                              // the addend: rounds the product's upper half
 }
 
-template <bool kHasZero>
-__device__ __forceinline__ void gq_fragments(const GqWords& x, half8& b_re, half8& b_im) {
+// The fp16 MFMA operand is the UPPER HALF of the int32 product (a Q14 number, |.| <= 2^14), rounded by the dot product's
+// addend and converted half to half (v_cvt_f16_i16 reading word 1: no shift, no int32 -> fp32 -> scale -> fp16 chain).
+// Dropping the lower half costs 2^-15 of full scale per element, a tenth of the fp16 rounding that follows; the factor
+// kGqOutputScale restores the scale at the output.
+constexpr float kGqOutputScale = 65536.0f / (32767.0f * 32767.0f) / 960.0f;
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void gq_fragments(const GqWords& x, bool has_zero, half8& b_re, half8& b_im) {
   unsigned wm[8], wn[8], wq[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -696,43 +704,42 @@ __device__ __forceinline__ void gq_fragments(const GqWords& x, half8& b_re, half
   int ri[8], ii[8];
   gq_dots(wm, wn, ri);                                              // Re = (mr, mi) . (nr, ni)
   gq_dots(wm, wq, ii);                                              // Im = (mr, mi) . (ni, -nr)
-  f32x4 re[2], im[2];
+  if (has_zero) {                                                   // (wavefront-uniform: the frame has a silent bin somewhere)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                                   // a silent channel's word is 0: factor 1
+      const bool z = wm[j] == 0u || wn[j] == 0u;
+      ri[j] = z ? kQ15One : ri[j];
+      ii[j] = z ? 0 : ii[j];
+    }
+  }
+  i16x4 re[2], im[2];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    int r = ri[j], i = ii[j];
-    if (kHasZero) {                                                 // a silent channel's word is 0: factor 1
-      const bool z = wm[j] == 0u || wn[j] == 0u;
-      r = z ? kQ15One : r;
-      i = z ? 0 : i;
-    }
-    re[j >> 2][j & 3] = static_cast<float>(r);
-    im[j >> 2][j & 3] = static_cast<float>(i);
+    re[j >> 2][j & 3] = static_cast<short>(ri[j] >> 16);
+    im[j >> 2][j & 3] = static_cast<short>(ii[j] >> 16);
   }
-  const float s = 1.0f / (32767.0f * 32767.0f);
-  const half4 r0 = __builtin_convertvector(re[0] * s, half4), r1 = __builtin_convertvector(re[1] * s, half4);
-  const half4 i0 = __builtin_convertvector(im[0] * s, half4), i1 = __builtin_convertvector(im[1] * s, half4);
+  const half4 r0 = __builtin_convertvector(re[0], half4), r1 = __builtin_convertvector(re[1], half4);
+  const half4 i0 = __builtin_convertvector(im[0], half4), i1 = __builtin_convertvector(im[1], half4);
   b_re = __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7);
   b_im = __builtin_shufflevector(i0, i1, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// One frame (both pair tiles when kTiles == 2) by one wavefront; `u` = the wavefront's frame in LDS; om / on = byte offsets
-// of the rows of the lane's pairs' channels (gq_pair_rows: loop invariant, and pair_channels reads a table from global
-// memory -- inside the frame loop its vmcnt(0) would also wait for the next frame's requests).
-template <bool kHasZero, int kTiles>
-__device__ __forceinline__ void gcc_q15_frame(const unsigned char* u, const half8* table, int lane, const int (&om)[2],
-                                              const int (&on)[2], f32x4 (&acc_c)[kTiles][kGmLagTiles],
-                                              f32x4 (&acc_s)[kTiles][kGmLagTiles]) {
+// One pair tile of one frame by one wavefront; `u` = the frame in LDS; om / on = byte offsets of the rows of the channels
+// of the lane's pair (loop invariant, and pair_channels reads a table from global memory: inside the frame loop its
+// vmcnt(0) would also wait for the next frame's requests).
+template <typename PerStep>
+__device__ __forceinline__ void gcc_q15_tile(const unsigned char* u, const half8* table, int lane, int om, int on,
+                                             bool has_zero, f32x4 (&acc_c)[kGmLagTiles], f32x4 (&acc_s)[kGmLagTiles],
+                                             PerStep&& per_step) {
   const int g = lane >> 4;
   // the lane's two units (bins 0..3 | 4..7 of bin group 4 ks + g) within a row; step ks adds 128 bytes.  The last step
   // reads bin group 60 for every lane (groups 61..63 do not exist; their table rows are zero).
   const int lo = (2 * g + (g & 1)) * 16, hi = (2 * g + 1 - (g & 1)) * 16;
   const half8* tab = table + lane;
 #pragma unroll
-  for (int tile = 0; tile < kTiles; ++tile)
+  for (int tl = 0; tl < kGmLagTiles; ++tl)
 #pragma unroll
-    for (int tl = 0; tl < kGmLagTiles; ++tl)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc_c[tile][tl][i] = acc_s[tile][tl][i] = 0.0f;
+    for (int i = 0; i < 4; ++i) acc_c[tl][i] = acc_s[tl][i] = 0.0f;
   struct TableFrags { half8 c[kGmLagTiles], s[kGmLagTiles]; };
   auto table_load = [&](int ks, TableFrags& tf) {
 #pragma unroll
@@ -741,42 +748,35 @@ __device__ __forceinline__ void gcc_q15_frame(const unsigned char* u, const half
       tf.s[tl] = tab[((1 * kGmLagTiles + tl) * kGmKSteps + ks) * 64];
     }
   };
-  auto words_load = [&](int ks, int tile, GqWords& w) {
+  auto words_load = [&](int ks, GqWords& w) {
     const bool last = ks == kGmKSteps - 1;                         // compile-time per unrolled step
     const int l = last ? 120 * 16 : lo + 128 * ks, h = last ? 121 * 16 : hi + 128 * ks;
-    w.m0 = *reinterpret_cast<const u32x4*>(u + om[tile] + l);
-    w.m1 = *reinterpret_cast<const u32x4*>(u + om[tile] + h);
-    w.n0 = *reinterpret_cast<const u32x4*>(u + on[tile] + l);
-    w.n1 = *reinterpret_cast<const u32x4*>(u + on[tile] + h);
+    w.m0 = *reinterpret_cast<const u32x4*>(u + om + l);
+    w.m1 = *reinterpret_cast<const u32x4*>(u + om + h);
+    w.n0 = *reinterpret_cast<const u32x4*>(u + on + l);
+    w.n1 = *reinterpret_cast<const u32x4*>(u + on + h);
   };
-  // A step: the phase factors of both tiles (vector units), then the twelve products.  Single buffers: the next step's
-  // words are requested once the fragments are formed (they arrive under the products), the next step's table
-  // fragments once the products are issued (they arrive under the next step's vector work).  Requesting everything a
-  // whole step ahead instead needs 70 more registers, and with those the compiler parked the NEXT FRAME's requests in
-  // accumulator registers -- waiting for them at the start of the frame.
-  GqWords w[kTiles];
+  // The table is the A operand (rows = lags), the phase factors the B operand (columns = pairs): a lane then holds FOUR
+  // CONSECUTIVE lags of one pair and stores them as one 16-byte vector.  Single buffers (two wavefronts per SIMD: 256
+  // registers each): the next step's words are requested once the fragments are formed, the next step's table
+  // fragments once the products are issued; the partner wavefront of the SIMD (the frame's other tile) fills what
+  // latency that leaves.
+  GqWords w;
   TableFrags tf;
-#pragma unroll
-  for (int tile = 0; tile < kTiles; ++tile) words_load(0, tile, w[tile]);
+  words_load(0, w);
   table_load(0, tf);
 #pragma unroll
   for (int ks = 0; ks < kGmKSteps; ++ks) {                   // fully unrolled: every LDS offset is an immediate
-    half8 b_re[kTiles], b_im[kTiles];
-#pragma unroll
-    for (int tile = 0; tile < kTiles; ++tile) gq_fragments<kHasZero>(w[tile], b_re[tile], b_im[tile]);
+    half8 b_re, b_im;
+    gq_fragments(w, has_zero, b_re, b_im);
     __builtin_amdgcn_sched_barrier(0);
-    if (ks + 1 < kGmKSteps) {
-#pragma unroll
-      for (int tile = 0; tile < kTiles; ++tile) words_load(ks + 1, tile, w[tile]);
-    }
+    if (ks + 1 < kGmKSteps) words_load(ks + 1, w);
+    per_step(ks);                                            // (the kernel's loop: one of the next frame's requests)
     __builtin_amdgcn_sched_barrier(0);                       // (left alone the scheduler sinks the reads to their use)
 #pragma unroll
-    for (int tile = 0; tile < kTiles; ++tile) {
-#pragma unroll
-      for (int tl = 0; tl < kGmLagTiles; ++tl) {
-        acc_c[tile][tl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tf.c[tl], b_re[tile], acc_c[tile][tl], 0, 0, 0);
-        acc_s[tile][tl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tf.s[tl], b_im[tile], acc_s[tile][tl], 0, 0, 0);
-      }
+    for (int tl = 0; tl < kGmLagTiles; ++tl) {
+      acc_c[tl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tf.c[tl], b_re, acc_c[tl], 0, 0, 0);
+      acc_s[tl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tf.s[tl], b_im, acc_s[tl], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (ks + 1 < kGmKSteps) table_load(ks + 1, tf);
@@ -784,38 +784,50 @@ __device__ __forceinline__ void gcc_q15_frame(const unsigned char* u, const half
   }
 }
 
+// kTiles wavefronts per frame, one pair tile each; four frames ("slots") per workgroup: wavefront w takes tile w >> 2 of
+// slot w & 3 (the hardware deals a workgroup's wavefronts to the four SIMDs in turn, so a frame's two tiles share a
+// SIMD and one's vector work fills the other's matrix-core, LDS-issue and wait cycles: alone on its SIMD a wavefront
+// needs 480 cycles per 32-bin step -- the sum of what it issues -- two together 370 each).  The loop alternates two
+// intervals separated by workgroup barriers: "products" -- the matrix-core transform of the staged frame, with the next
+// frame's requests spread over its steps, then the stores -- and "copy" -- the requested words to LDS.  Running the two
+// halves of the workgroup in antiphase (one computes while the other copies) was measured too: 3 % slower, the lone
+// wavefront's 480 cycles per step cost more than the hidden copy saves.
 template <int kTiles>
-__global__ __launch_bounds__(kGmThreads, 1) void gcc_q15_kernel(GccMfmaArgs a) {
+__global__ __launch_bounds__(kTiles * kGqFrames * 64) void gcc_q15_kernel(GccMfmaArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int kThreads = kTiles * kGqFrames * 64;
+  constexpr int kRounds = kGqUnitsPerLane / kTiles;                // copy rounds per wavefront: the frame's tiles share the copy
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int tile = wave / kGqFrames, slot = wave & (kGqFrames - 1);
   const half8* table = reinterpret_cast<const half8*>(smem_raw);
-  unsigned char* u = smem_raw + kGmTableBytes + wave * kGqFrameBytes;      // this wavefront's frame
+  unsigned char* u = smem_raw + kGmTableBytes + slot * kGqFrameBytes;      // this wavefront's frame
+  int* flags = reinterpret_cast<int*>(smem_raw + kGmTableBytes + kGqFrames * kGqFrameBytes + kGqDumpBytes);   // [kGqFrames][2]
   {                                                                // the constant table, once per workgroup
     const uint4* src = static_cast<const uint4*>(a.table);
     uint4* dst = reinterpret_cast<uint4*>(smem_raw);
-    for (int i = tid; i < kGmTableBytes / 16; i += kGmThreads) dst[i] = src[i];
+    for (int i = tid; i < kGmTableBytes / 16; i += kThreads) dst[i] = src[i];
+    if (tid < 2 * kGqFrames) flags[tid] = 0;
   }
   const int n_pairs = static_cast<int>(a.C * (a.C - 1) / 2);
   const int n_ch = static_cast<int>(a.C);
-  const long total = a.N * a.F;
-  // Lane `lane` copies units lane + 64 i of the frame (unit = 16 bytes = 4 bins; row c = units 122 c ..): where from and
-  // where to is loop invariant.  Rows of channels the clip does not have are never read by a pair.  Words 481..487 of a
-  // row are whatever the log-mel pass left there (it never writes them): they meet zero table rows, and an integer
-  // product is finite whatever the words are.
-  const uint4* spec = reinterpret_cast<const uint4*>(a.spec);
-  const unsigned ch_stride = static_cast<unsigned>(a.F) * kGqRowUnits;     // units; the host checks C F 488 < 2^31
+  // Lane `lane` of tile t copies units lane + 64 (kRounds t + i) of the frame (unit = 16 bytes = 4 bins; row c = units
+  // 122 c ..): where from and where to is loop invariant.  Rows of channels the clip does not have are never read by a
+  // pair.  Words 481..487 of a row are whatever the log-mel pass left there (it never writes them): they meet zero table
+  // rows, and an integer product is finite whatever the words are.
   // Every lane loads and stores in every round -- a lane with nothing to copy reads unit 0 and writes to a dump slot
   // past the frames: a load or a copy under a lane mask leaves the compiler unable to tell whether the request is still
   // outstanding, and it then waits for ALL memory operations (vmcnt(0), the output stores included) wherever it reuses
   // the register.
-  unsigned src_off[kGqUnitsPerLane];
-  int dst_off[kGqUnitsPerLane];
+  const uint4* spec = reinterpret_cast<const uint4*>(a.spec);
+  const unsigned ch_stride = static_cast<unsigned>(a.F) * kGqRowUnits;     // units; the host checks C F 488 < 2^31
+  unsigned src_off[kRounds];
+  int dst_off[kRounds];
   unsigned all_mask = 0, first_mask = 0;                           // per round: all four words are bins | only the first is
-  const int dump_off = kGmWaves * kGqFrameBytes - wave * kGqFrameBytes + lane * 16;    // relative to u
+  const int dump_off = (kGqFrames - slot) * kGqFrameBytes + lane * 16;     // relative to u
 #pragma unroll
-  for (int i = 0; i < kGqUnitsPerLane; ++i) {
-    const int unit = lane + 64 * i;
+  for (int i = 0; i < kRounds; ++i) {
+    const int unit = lane + 64 * (kRounds * tile + i);
     const int c = unit / kGqRowUnits, ir = unit - c * kGqRowUnits;
     const bool valid = unit < kGqFrameUnits && c < n_ch;
     src_off[i] = valid ? static_cast<unsigned>(c) * ch_stride + static_cast<unsigned>(ir) : 0u;
@@ -823,64 +835,70 @@ __global__ __launch_bounds__(kGmThreads, 1) void gcc_q15_kernel(GccMfmaArgs a) {
     all_mask |= valid && ir < (kBins - 1) / 4 ? 1u << i : 0u;      // units 0..119: bins 0..479
     first_mask |= valid && ir == (kBins - 1) / 4 ? 1u << i : 0u;   // unit 120: bin 480 and three words past the row
   }
-  auto frame_base = [&](long f) {
-    const long n = f / a.F;
-    return spec + (n * a.C * a.F + (f - n * a.F)) * kGqRowUnits;
+  // frame indices are 32-bit (the host checks N F < 2^31): a 64-bit division is ~120 instructions
+  const unsigned total = static_cast<unsigned>(a.N * a.F), n_frames = static_cast<unsigned>(a.F);
+  auto frame_base = [&](unsigned f) {                              // a frame past the end: the last one (copied, not used)
+    f = f < total ? f : total - 1;
+    const unsigned n = f / n_frames, t = f - n * n_frames;
+    return spec + (static_cast<unsigned long>(n) * static_cast<unsigned long>(a.C * a.F) + t) * kGqRowUnits;
   };
-  int om[2] = {0, 0}, on[2] = {0, 0};                              // rows of the channels of the lane's pair, per tile
-#pragma unroll
-  for (int tile = 0; tile < kTiles; ++tile) {
+  int om, on;                                                      // rows of the channels of the lane's pair
+  {
     int p = 16 * tile + (lane & 15);
     if (p >= n_pairs) p = n_pairs - 1;                             // rows past the last pair repeat it (never stored)
     int cm, cn;
     pair_channels(p, n_ch, cm, cn);
-    om[tile] = cm * kGqRowBytes;
-    on[tile] = cn * kGqRowBytes;
+    om = cm * kGqRowBytes;
+    on = cn * kGqRowBytes;
   }
-  uint4 pre[kGqUnitsPerLane];
+  uint4 pre[kRounds];
   auto request = [&](const uint4* src) {
 #pragma unroll
-    for (int i = 0; i < kGqUnitsPerLane; ++i) pre[i] = src[src_off[i]];
+    for (int i = 0; i < kRounds; ++i) pre[i] = src[src_off[i]];
   };
-  auto stage = [&]() {                                             // requested words -> LDS; true if a bin of the frame is silent
+  auto copy = [&]() {                                              // requested words -> LDS, and this half's silent-bin flag
     bool zero = false;
 #pragma unroll
-    for (int i = 0; i < kGqUnitsPerLane; ++i) {
+    for (int i = 0; i < kRounds; ++i) {
       const uint4 w = pre[i];
       *reinterpret_cast<uint4*>(u + dst_off[i]) = w;
       const bool z_first = w.x == 0u;
       const bool z_all = z_first | (w.y == 0u) | (w.z == 0u) | (w.w == 0u);
-      zero |= ((all_mask >> i & 1) != 0 & z_all) | ((first_mask >> i & 1) != 0 & z_first);
+      zero |= (((all_mask >> i) & 1u) != 0u && z_all) | (((first_mask >> i) & 1u) != 0u && z_first);
     }
-    return __builtin_amdgcn_ballot_w64(zero) != 0;
+    const bool any = __builtin_amdgcn_ballot_w64(zero) != 0;
+    if (lane == 0) flags[2 * slot + tile] = any ? 1 : 0;           // (a word per wavefront: nothing to clear, no race)
   };
-  const long stride = static_cast<long>(kGmWaves) * gridDim.x;
-  long f = static_cast<long>(kGmWaves) * blockIdx.x + wave;
-  if (f < total) request(frame_base(f));
-  __syncthreads();                                                 // the table is in place; no barrier after this one
-  bool has_zero = false;
-  if (f < total) {
-    has_zero = stage();
-    __builtin_amdgcn_sched_barrier(0);
-    if (f + stride < total) request(frame_base(f + stride));
-  }
-  // Order within an iteration: products of frame f | next frame's words -> LDS | frame f's stores | requests for the frame
-  // after next.  (Stores and loads share the vmcnt counter, which retires in order: with the stores issued BEFORE the
-  // copy, the copy's wait for the requests would also wait for the stores' acknowledgements, issued moments earlier.)
-  for (; f < total; f += stride) {                                 // trip count per WAVEFRONT
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the frame is in LDS (same wavefront: no barrier)
-    const long n = f / a.F;
-    const long t = f - n * a.F;
-    f32x4 acc_c[kTiles][kGmLagTiles], acc_s[kTiles][kGmLagTiles];
-    if (has_zero) gcc_q15_frame<true, kTiles>(u, table, lane, om, on, acc_c, acc_s);
-    else gcc_q15_frame<false, kTiles>(u, table, lane, om, on, acc_c, acc_s);
-    if (f + stride < total) has_zero = stage();
-#pragma unroll
-    for (int tile = 0; tile < kTiles; ++tile)
-      gm_store_pairs(a, acc_c[tile], acc_s[tile], 16 * tile + (lane & 15), lane >> 4, n_pairs, n, t);
-    __builtin_amdgcn_sched_barrier(0);
-    if (f + 2 * stride < total) request(frame_base(f + 2 * stride));       // in flight across the next frame's products
-    __builtin_amdgcn_sched_barrier(0);
+  const unsigned stride = kGqFrames * gridDim.x;
+  const unsigned first = kGqFrames * blockIdx.x;                   // < total: the host launches at most ceil(total / 4) workgroups
+  const unsigned n_iter = (total - first + stride - 1) / stride;   // frames per slot, the same for the whole workgroup
+  unsigned f = first + slot;
+  request(frame_base(f));
+  __syncthreads();                                                 // the table and the cleared flags are in place
+  copy();
+  lds_barrier();
+  for (unsigned it = 0; it < n_iter; ++it) {                       // uniform trip count
+    {
+      const int has_zero = flags[2 * slot] | flags[2 * slot + 1];
+      // the next frame's requests go out one per step of the products (a CU issues vector memory instructions at about
+      // 16 bytes per cycle: all wavefronts issuing theirs at once between the barriers took 2 000 cycles per frame)
+      const uint4* next = frame_base(f + stride);
+      auto per_step = [&](int ks) {
+        if (ks < kRounds) pre[ks] = next[src_off[ks]];
+      };
+      // (a slot past its last frame still runs the products, on whatever its LDS holds, and stores nothing: one
+      // definition of the requests in the loop, which the register allocator needs to keep them where they land)
+      f32x4 acc_c[kGmLagTiles], acc_s[kGmLagTiles];
+      gcc_q15_tile(u, table, lane, om, on, has_zero != 0, acc_c, acc_s, per_step);
+      if (f < total) {
+        const unsigned n = f / n_frames, t = f - n * n_frames;
+        gm_store_pairs(a, acc_c, acc_s, 16 * tile + (lane & 15), lane >> 4, n_pairs, n, t, kGqOutputScale);
+      }
+      f += stride;
+    }
+    lds_barrier();                                                 // every reader of the frames and of the flags is done
+    copy();                                                        // (after the last frame: of a frame nobody reads)
+    lds_barrier();                                                 // the next frame and its flags are in LDS
   }
 }
 
@@ -970,13 +988,13 @@ static int launch_gcc_q15(seld::DeviceState* st, const uint32_t* phasors, int64_
     hipLaunchKernelGGL(gcc_mfma_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(kGmThreads), kGmLdsBytes,
                        static_cast<hipStream_t>(stream_), a);
   } else {
-    long blocks = (N * F + kGmWaves - 1) / kGmWaves;
+    long blocks = (N * F + kGqFrames - 1) / kGqFrames;
     if (blocks > st->num_cus) blocks = st->num_cus;
-    if (C * (C - 1) / 2 > 16)                                 // 7 or 8 channels: two tiles of 16 pairs
-      hipLaunchKernelGGL(gcc_q15_kernel<2>, dim3(static_cast<unsigned>(blocks)), dim3(kGmThreads), kGqLdsBytes,
+    if (C * (C - 1) / 2 > 16)                                 // 7 or 8 channels: two tiles of 16 pairs, a wavefront each
+      hipLaunchKernelGGL(gcc_q15_kernel<2>, dim3(static_cast<unsigned>(blocks)), dim3(2 * kGqFrames * 64), kGqLdsBytes,
                          static_cast<hipStream_t>(stream_), a);
     else
-      hipLaunchKernelGGL(gcc_q15_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(kGmThreads), kGqLdsBytes,
+      hipLaunchKernelGGL(gcc_q15_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(kGqFrames * 64), kGqLdsBytes,
                          static_cast<hipStream_t>(stream_), a);
   }
   SELD_HIP_TRY(hipGetLastError());
@@ -992,6 +1010,7 @@ int seld_gcc_phat_q15(const uint32_t* phasors, int64_t N, int64_t C, int64_t F, 
   if (N <= 0 || F <= 0) return fail(kErrInvalidArgument, "seld_gcc_phat_q15: N and F must be positive");
   if (C < 2 || C > 8) return fail(kErrUnsupported, "seld_gcc_phat_q15: 2..8 channels");
   if (C * F * kPhasorPitch >= (1L << 31)) return fail(kErrUnsupported, "seld_gcc_phat_q15: a clip's phasors exceed 2^31 words");
+  if (N * F + 4L * 1024 >= (1L << 31)) return fail(kErrUnsupported, "seld_gcc_phat_q15: more than 2^31 frames");
   // the kernel stores four consecutive lags as one vector: unit lag stride, 16-byte aligned rows
   const bool vector_rows = sM == 1 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && sN % 4 == 0 && sC % 4 == 0 && sT % 4 == 0;
   if (!vector_rows) return fail(kErrUnsupported, "seld_gcc_phat_q15: needs unit lag stride and 16-byte aligned rows");
