@@ -628,7 +628,7 @@ def main():
                        "optimizer_iterations_per_step": windows_per_step // BATCH,
                        "parallelism": f"dp{world}", "windows_per_s": clips * 60 / elapsed,
                        "final_loss": float(loss.item())},
-            "roofline": {"kernel": "seld::logmel_main_kernel<float, false> (fused STFT+mel+dB; the edge iterations are its "
+            "roofline": {"kernel": "seld::logmel_main_kernel<float, 0> (fused STFT+mel+dB; the edge iterations are its "
                                    "trailing workgroups)"
                          if args.features == "logmel" else f"feature phase: {'seld::logmel_main_kernel<float, 2> (log-mel + Q15 phasors) + seld::gcc_q15_kernel<2>' if args.features == 'logmel_gcc' else 'seld::logmel_main_kernel<float, 1> (log-mel + spectra) + seld::foa_iv_kernel'}",
                          "bound": "hbm",
