@@ -659,7 +659,6 @@ __device__ __forceinline__ int gq_unit_slot(int i) { return (i & ~1) | ((i ^ (i 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kQ15One = 32767 * 32767;                             // the integer product that stands for 1.0
 
 struct GqWords {               // 8 bins of the two channels of a pair, one Q15 word (re | im << 16) each
   u32x4 m0, m1, n0, n1;
@@ -704,13 +703,24 @@ __device__ __forceinline__ void gq_fragments(const GqWords& x, bool has_zero, ha
   int ri[8], ii[8];
   gq_dots(wm, wn, ri);                                              // Re = (mr, mi) . (nr, ni)
   gq_dots(wm, wq, ii);                                              // Im = (mr, mi) . (ni, -nr)
-  if (has_zero) {                                                   // (wavefront-uniform: the frame has a silent bin somewhere)
+  if (has_zero) {
+    // (wavefront-uniform, rare: the frame has a silent bin somewhere.)  A silent channel's word is 0 and its factor is
+    // 1 -- which the Q14 operand cannot carry exactly: 32767^2 / 65536 = 16383.0002 rounds to 16384 in fp16, 6.1e-5 too
+    // much at lag 0 of a silent pair.  Such frames take the exact route instead: int32 -> fp32 -> 1 / 32767^2 -> ONE
+    // rounding to fp16, operands in [-1, 1], and the output scale 1 / 960 (the caller picks the scale by the same flag).
+    f32x4 fr[2], fi[2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {                                   // a silent channel's word is 0: factor 1
+    for (int j = 0; j < 8; ++j) {
       const bool z = wm[j] == 0u || wn[j] == 0u;
-      ri[j] = z ? kQ15One : ri[j];
-      ii[j] = z ? 0 : ii[j];
+      const float s = 1.0f / (32767.0f * 32767.0f);
+      fr[j >> 2][j & 3] = z ? 1.0f : static_cast<float>(ri[j] - (1 << 15)) * s;     // (without the rounding addend)
+      fi[j >> 2][j & 3] = z ? 0.0f : static_cast<float>(ii[j] - (1 << 15)) * s;
     }
+    const half4 r0 = __builtin_convertvector(fr[0], half4), r1 = __builtin_convertvector(fr[1], half4);
+    const half4 i0 = __builtin_convertvector(fi[0], half4), i1 = __builtin_convertvector(fi[1], half4);
+    b_re = __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7);
+    b_im = __builtin_shufflevector(i0, i1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return;
   }
   i16x4 re[2], im[2];
 #pragma unroll
@@ -892,7 +902,8 @@ __global__ __launch_bounds__(kTiles * kGqFrames * 64) void gcc_q15_kernel(GccMfm
       gcc_q15_tile(u, table, lane, om, on, has_zero != 0, acc_c, acc_s, per_step);
       if (f < total) {
         const unsigned n = f / n_frames, t = f - n * n_frames;
-        gm_store_pairs(a, acc_c, acc_s, 16 * tile + (lane & 15), lane >> 4, n_pairs, n, t, kGqOutputScale);
+        gm_store_pairs(a, acc_c, acc_s, 16 * tile + (lane & 15), lane >> 4, n_pairs, n, t,
+                       has_zero ? 1.0f / 960.0f : kGqOutputScale);
       }
       f += stride;
     }

@@ -202,3 +202,58 @@ def test_gcc_table_reproduces_irfft_lags():
     err = np.abs(got - ref)
     assert err.max() <= 6e-5, err.max()
     assert np.sqrt((err ** 2).mean()) <= 1.5e-5
+
+
+def test_gcc_q15_arithmetic_model():
+    """The rounding points of gcc_q15_kernel (csrc/spatial.hip, gq_fragments) restated with numpy on the kernel's own
+    table: phasors as Q15 words (round to nearest of 32767 x), the two pair products exact in int32, their UPPER HALF
+    after the rounding addend 2^15 (a Q14 integer) converted to fp16, fp32 accumulation, output scale 65536 / 32767^2 /
+    960 -- against numpy's irfft of the exact phase factors conj(Um) Un.  Holds the 1e-4 bar of the GPU tests with the
+    margin DESIGN.md 7.3 quotes; and why frames with a silent channel (word 0) go another way."""
+    import ctypes
+    import numpy as np
+    import seld_native
+    lib = seld_native.load_library()
+    halves = np.zeros(2 * 3 * 16 * 64 * 8, dtype=np.uint16)
+    assert lib.seld_gcc_table_host(halves.ctypes.data_as(ctypes.c_void_p)) == 0
+    frag = halves.view(np.float16).astype(np.float32).reshape(2, 3, 16, 64, 8)
+    table = np.zeros((2, 48, 512), dtype=np.float32)
+    for tile in range(3):
+        for ks in range(16):
+            for lane in range(64):
+                table[:, 16 * tile + (lane & 15), 32 * ks + 8 * (lane >> 4):32 * ks + 8 * (lane >> 4) + 8] = \
+                    frag[:, tile, ks, lane, :]
+    rng = np.random.default_rng(11)
+    rows = 3000
+    um = np.exp(1j * rng.uniform(-np.pi, np.pi, size=(rows, 481)))
+    un = np.exp(1j * rng.uniform(-np.pi, np.pi, size=(rows, 481)))
+    un[:200] = um[:200] * np.exp(-2j * np.pi * np.arange(481) * 7 / 960)              # a pure delay: R on the unit circle, structured
+    q = lambda x: np.clip(np.rint(x * 32767.0), -32767, 32767).astype(np.int64)
+    mr, mi, nr, ni = q(um.real), q(um.imag), q(un.real), q(un.imag)
+    assert max(np.abs(mr).max(), np.abs(ni).max()) <= 32767
+    re, im = mr * nr + mi * ni, mr * ni - mi * nr                                     # v_dot2_i32_i16: exact, |.| < 2^31
+    assert np.abs(re).max() < 2 ** 31 and np.abs(im).max() < 2 ** 31
+    upper = lambda v: np.floor_divide(v + 32768, 65536)                               # addend 2^15, then bits 31..16 (arithmetic)
+    re16 = upper(re).astype(np.float16).astype(np.float32)                            # v_cvt_f16_i16
+    im16 = upper(im).astype(np.float16).astype(np.float32)
+    c = (re16 @ table[0, :, :481].T).astype(np.float64)
+    s_ = (im16 @ table[1, :, :481].T).astype(np.float64)
+    scale = 65536.0 / (32767.0 * 32767.0) / 960.0
+    got = np.concatenate([((c - s_) * scale)[:, 32:0:-1], ((c + s_) * scale)[:, 0:32]], axis=1)     # lags -32..31
+    cc = np.fft.irfft(np.conj(um) * un, n=960, axis=1)
+    ref = np.concatenate([cc[:, 928:960], cc[:, 0:32]], axis=1)
+    err = np.abs(got - ref)
+    assert err.max() <= 7e-5, err.max()
+    assert np.sqrt((err ** 2).mean()) <= 1.5e-5
+    assert (got[:200].argmax(axis=1) == 32 + 7).all()                                # the planted delay is the peak
+    # The factor 1 of a silent channel is NOT representable on that scale -- 32767^2 / 65536 = 16383.0002 is 16384 in fp16,
+    # 6.1e-5 too much at lag 0 -- which is why frames with a silent bin take the kernel's exact route (fp32 products, one
+    # rounding to fp16, operands in [-1, 1], output scale 1 / 960): there the unit pulse is exact to the table's rounding.
+    q14_one = upper(np.full((1, 481), 32767 * 32767, dtype=np.int64)).astype(np.float16).astype(np.float32)
+    assert abs(float((q14_one @ table[0, 0, :481]) * scale) - 1.0) > 5e-5
+    one = np.ones((1, 481), dtype=np.float16).astype(np.float32)
+    c1 = (one @ table[0, :, :481].T).astype(np.float64) / 960.0
+    pulse = np.concatenate([c1[:, 32:0:-1], c1[:, 0:32]], axis=1)
+    want = np.zeros(64)
+    want[32] = 1.0
+    assert np.abs(pulse[0] - want).max() <= 1e-5

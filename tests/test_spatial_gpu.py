@@ -93,7 +93,7 @@ def test_gcc_phat_with_a_silent_channel(gpu_device, kernel, monkeypatch):
     dead = [1, 3, 5]                                                      # pairs (0,2), (1,2), (2,3) in lexicographic order
     pulse = np.zeros(64)
     pulse[32] = 1.0
-    assert np.abs(got[dead] - pulse[None, :, None]).max() <= 1e-4
+    assert np.abs(got[dead] - pulse[None, :, None]).max() <= 2e-5         # (frames with a silent bin take the exact route)
 
 
 def test_gcc_phat_full_size_clip_and_kernel_variants(gpu_device, monkeypatch):
