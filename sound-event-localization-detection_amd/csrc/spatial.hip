@@ -407,24 +407,36 @@ __device__ __forceinline__ void gm_fragments(const GmPhasors& x, half8& a_re, ha
 }
 
 // cc[+l] = (C[l] + S[l]) / 960 at index 32 + l (l = 0..31),  cc[-l] = (C[l] - S[l]) / 960 at index 32 - l (l = 1..32);
-// the lag stride of the output is 1 (the host checks): 16-byte stores, the second set at a 4-byte aligned address.
-// `scale` = 1 / 960 times whatever factor the caller left out of its phase factors.
+// the lag stride of the output is 1 and rows are 16-byte aligned (the host checks).  A lane holds lags l0 .. l0 + 3
+// (l0 = 16 tile + 4 g) of its pair: the positive ones are one aligned 16-byte store at 32 + l0; the negative ones, reversed,
+// would start at 29 - l0 -- one float off alignment -- so each lane instead takes the value of lag l0 + 4 from its
+// neighbour (lane + 16: the next group of four lags, or for g = 3 group 0's first lag of the next tile) and stores lags
+// l0 + 4 .. l0 + 1 at 28 - l0, aligned; that also covers lag -32 (index 0), and index 32 (lag 0) is the positive store's.
+// Four aligned stores per lane instead of two aligned, two unaligned and a single float (same speed, measured A/B on one
+// box: the stores are a tenth of the frame and issue-bound either way; kept for the fewer memory transactions).
+// `scale` = 1 / 960 times whatever factor the caller left out of its phase factors.  Called by whole wavefronts.
 __device__ __forceinline__ void gm_store_pairs(const GccMfmaArgs& a, const f32x4 (&acc_c)[kGmLagTiles],
                                                const f32x4 (&acc_s)[kGmLagTiles], int pair, int g, int n_pairs, long n,
                                                long t, float scale = 1.0f / 960.0f) {
+  float first[kGmLagTiles];                                          // (C - S) of each tile's first lag, this lane's group
+#pragma unroll
+  for (int tl = 0; tl < kGmLagTiles; ++tl) first[tl] = (acc_c[tl][0] - acc_s[tl][0]) * scale;
+  const int from = ((static_cast<int>(threadIdx.x) + 16) & 63) << 2;   // the lane 16 further (g + 1; g = 3 wraps to g = 0)
+  float next[2];
+#pragma unroll
+  for (int tl = 0; tl < 2; ++tl)
+    next[tl] = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(g == 0 ? first[tl + 1] : first[tl])));
   if (pair >= n_pairs) return;
   float* op = a.out + n * a.sN + pair * a.sC + t * a.sT;
 #pragma unroll
   for (int tl = 0; tl < 2; ++tl) {
     const int l0 = 16 * tl + 4 * g;
     const f32x4 plus = (acc_c[tl] + acc_s[tl]) * scale;
-    const f32x4 minus = (acc_c[tl] - acc_s[tl]) * scale;           // at l0 = 0 its first value is cc[0] again (S[0] = 0)
+    const f32x4 minus = (acc_c[tl] - acc_s[tl]) * scale;
     *reinterpret_cast<f32x4*>(op + 32 + l0) = plus;
-    struct __attribute__((packed, aligned(4))) Unaligned4 { float v[4]; };
-    Unaligned4 rev = {{minus[3], minus[2], minus[1], minus[0]}};
-    *reinterpret_cast<Unaligned4*>(op + 29 - l0) = rev;
+    const f32x4 rev = {next[tl], minus[3], minus[2], minus[1]};      // lags -(l0 + 4) .. -(l0 + 1)
+    *reinterpret_cast<f32x4*>(op + 28 - l0) = rev;
   }
-  if (g == 0) op[0] = (acc_c[2][0] - acc_s[2][0]) * scale;         // lag -32
 }
 
 template <bool kHasZero>
@@ -722,16 +734,37 @@ __device__ __forceinline__ void gq_fragments(const GqWords& x, bool has_zero, ha
     b_im = __builtin_shufflevector(i0, i1, 0, 1, 2, 3, 4, 5, 6, 7);
     return;
   }
-  i16x4 re[2], im[2];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    re[j >> 2][j & 3] = static_cast<short>(ri[j] >> 16);
-    im[j >> 2][j & 3] = static_cast<short>(ii[j] >> 16);
-  }
-  const half4 r0 = __builtin_convertvector(re[0], half4), r1 = __builtin_convertvector(re[1], half4);
-  const half4 i0 = __builtin_convertvector(im[0], half4), i1 = __builtin_convertvector(im[1], half4);
-  b_re = __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7);
-  b_im = __builtin_shufflevector(i0, i1, 0, 1, 2, 3, 4, 5, 6, 7);
+  // Word 1 of each product (its upper half) -> fp16, two products per register: v_cvt_f16_i16 with SDWA selects, the
+  // even bins into the low halves (high halves zeroed), then the odd bins into the high halves (low halves kept): 16
+  // instructions for the 16 values.  (Plain C++ gets a conversion per value plus a v_pack_b32_f16 per pair: 24.)  One
+  // statement because this target wants a wait state between a partial-register write (dst_sel) and a read of that
+  // register -- the second pass reads what the first wrote, eight instructions later, and the s_nop covers the
+  // consumer of the last.
+  unsigned p[8];
+  asm("v_cvt_f16_i16_sdwa %0, %8 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+      "v_cvt_f16_i16_sdwa %1, %10 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+      "v_cvt_f16_i16_sdwa %2, %12 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+      "v_cvt_f16_i16_sdwa %3, %14 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+      "v_cvt_f16_i16_sdwa %4, %16 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+      "v_cvt_f16_i16_sdwa %5, %18 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+      "v_cvt_f16_i16_sdwa %6, %20 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+      "v_cvt_f16_i16_sdwa %7, %22 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+      "v_cvt_f16_i16_sdwa %0, %9 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"
+      "v_cvt_f16_i16_sdwa %1, %11 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"
+      "v_cvt_f16_i16_sdwa %2, %13 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"
+      "v_cvt_f16_i16_sdwa %3, %15 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"
+      "v_cvt_f16_i16_sdwa %4, %17 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"
+      "v_cvt_f16_i16_sdwa %5, %19 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"
+      "v_cvt_f16_i16_sdwa %6, %21 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"
+      "v_cvt_f16_i16_sdwa %7, %23 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"
+      "s_nop 1"
+      : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]), "=&v"(p[7])
+      : "v"(ri[0]), "v"(ri[1]), "v"(ri[2]), "v"(ri[3]), "v"(ri[4]), "v"(ri[5]), "v"(ri[6]), "v"(ri[7]),
+        "v"(ii[0]), "v"(ii[1]), "v"(ii[2]), "v"(ii[3]), "v"(ii[4]), "v"(ii[5]), "v"(ii[6]), "v"(ii[7]));
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  const u32x4_t pr = {p[0], p[1], p[2], p[3]}, pi = {p[4], p[5], p[6], p[7]};
+  b_re = __builtin_bit_cast(half8, pr);
+  b_im = __builtin_bit_cast(half8, pi);
 }
 
 // One pair tile of one frame by one wavefront; `u` = the frame in LDS; om / on = byte offsets of the rows of the channels
