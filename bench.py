@@ -595,7 +595,9 @@ def main():
         out_of_sync = []
         if not in_sync:          # name the tensors that differ (a diagnostic: this never happens in a healthy run)
             with torch.no_grad():
-                each = torch.stack([p.double().sum() for p in hot.model.parameters()]).cpu()
+                each = torch.stack([p.double().sum() for p in hot.model.parameters()])
+            if backend != "nccl":             # RCCL moves device tensors only
+                each = each.cpu()
             both = [torch.zeros_like(each) for _ in range(world)]
             dist.all_gather(both, each)
             names = [n for n, _ in hot.model.named_parameters()]

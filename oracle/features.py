@@ -18,6 +18,8 @@ defaults:
 
 VALUE PARITY WITH TORCHAUDIO ITSELF IS UNPINNED (only the frame count is recorded by the
 reference: [4, 64, 4471] for L=2145600, SMR_SELD_2.ipynb:518-519).
+An independent third-party restatement (transformers.audio_utils) agrees to 1.3e-6 dB with one filterbank and 4.3e-5 dB
+with its own float64-built one (tests/test_oracle_cpu.py): corroboration, not a pin.
 
 Two restatements are provided:
   * ``logmel_torch``  -- fp32, ``torch.stft`` based: what the reference's CPU path computes.

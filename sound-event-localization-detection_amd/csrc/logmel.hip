@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kMainWaves * 64, 2) void logmel_main_kernel(LogmelA
     SELD_WAVE_SYNC();
     // the next iteration's samples: requested here, a whole un-pack + mel + store phase ahead -- except in the fp32
     // phasor instantiation, whose un-packing needs the 48 registers (requested after it: no scratch, 64 B per lane before)
-    constexpr bool kLatePrefetch = kSpec == 2 && sizeof(T) == 4;
+    constexpr bool kLatePrefetch = kSpec != 0 && sizeof(T) == 4;
     if (!kLatePrefetch) load_samples<T, true>(lane, pcm + nrow * a.L, a.L, nitr * kFramesPerIter + 2 * h, s);
     cf m[16];
     phase_c_load(lane, lds, m);

@@ -36,6 +36,7 @@ and replays.  Ragged last batches get their own graphs.  The learning rate is a 
 copied into, so a ReduceLROnPlateau step needs no re-capture."""
 import logging
 import os
+import time
 from contextlib import nullcontext
 
 import torch
@@ -390,6 +391,11 @@ class GraphedTrainStep:
     def _capture(self, st, spec, labels):
         st["spec"], st["labels"] = spec.clone(), labels.clone()
         torch.cuda.synchronize(self.device)
+        if self.world > 1 and dist.is_initialized() and dist.get_backend() == "nccl":
+            # the communicator's watchdog thread polls the events of the warm-up iterations' collectives (every 100 ms);
+            # an event query from another thread while a global-mode capture is open can invalidate the capture.  All
+            # of them are complete after the synchronisation above: give the watchdog one period to retire them.
+            time.sleep(0.3)
         graphs, k = [], 0
         while True:
             graph = torch.cuda.CUDAGraph()
