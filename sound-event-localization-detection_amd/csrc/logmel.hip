@@ -211,7 +211,6 @@ __global__ __launch_bounds__(kEdgeWaves * 64, 1) void logmel_edge_kernel(LogmelA
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const int h = lane >> 5;
   float* tab = smem;
   float* lds = smem + kTabFloats + wave * kLdsFloatsPerWave;
   fill_tables(a, tab, tid, kEdgeWaves * 64);

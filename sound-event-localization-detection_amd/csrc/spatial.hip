@@ -117,7 +117,6 @@ __global__ __launch_bounds__(kIvWaves * 64) void foa_iv_kernel(IvArgs a) {
 //     lag = k1 + 32 k2 :  k2 = 0 -> lags 0..31,   k2 = 29 -> lags 928..959 = -32..-1.
 constexpr int kGccWaves = 7;
 constexpr int kGccSpecFloats = 8 * kBins * 2;                      // 7696 floats
-constexpr int kGccTwFloats = 5 * 64 * 4;                           // two-level twiddle quads
 constexpr int kGccLdsFloats = kGccSpecFloats + kGccWaves * kEFloats;     // 142 KB: one workgroup per CU
 
 __constant__ unsigned char kPairM[28] = {0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6};
