@@ -353,7 +353,7 @@ def kernel_rooflines(device):
     # the FOA feature set: log-mel + spectra in one pass (logmel_main_kernel<float, 1>), then seld::foa_iv_kernel
     # (mel-projected intensity vectors): 4 x 5.76 MB PCM in + 7 x 64 x 3001 x 4 B out per clip
     pcm4 = torch.randn(clips, 4, CLIP_SAMPLES, device=device) * 0.1
-    hbm(f"spatial_features logmel_iv ({clips} clips x 4 ch FOA: logmel_main_kernel<float, 1> + foa_iv_kernel)",
+    hbm(f"spatial_features logmel_iv ({clips} clips x 4 ch FOA: logmel_iv_kernel<float>, one pass)",
         clips * (4 * CLIP_SAMPLES * 4 + 7 * 64 * (1 + CLIP_SAMPLES // 480) * 4),
         timeit(lambda: nat.spatial_features(pcm4, "logmel_iv"), reps=3))
     del pcm4
@@ -632,7 +632,7 @@ def main():
                        "final_loss": float(loss.item())},
             "roofline": {"kernel": "seld::logmel_main_kernel<float, 0> (fused STFT+mel+dB; the edge iterations are its "
                                    "trailing workgroups)"
-                         if args.features == "logmel" else f"feature phase: {'seld::logmel_main_kernel<float, 2> (log-mel + Q15 phasors) + seld::gcc_q15_kernel<2>' if args.features == 'logmel_gcc' else 'seld::logmel_main_kernel<float, 1> (log-mel + spectra) + seld::foa_iv_kernel'}",
+                         if args.features == "logmel" else f"feature phase: {'seld::logmel_main_kernel<float, 2> (log-mel + Q15 phasors) + seld::gcc_q15_kernel<2>' if args.features == 'logmel_gcc' else 'seld::logmel_iv_kernel<float> (log-mel + intensity vectors, one pass)'}",
                          "bound": "hbm",
                          "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS,

@@ -100,6 +100,14 @@ int seld_stft_i16(const int16_t* pcm, int64_t N, int64_t C, int64_t L, float* ou
 int seld_foa_intensity(const float* spec_complex, int64_t N, int64_t F, float* out, int64_t sN, int64_t sC,
                        int64_t sM, int64_t sT, void* stream);
 
+/* The FOA feature set in ONE pass over the PCM (pcm [N][4][L], channel 0 = W): log-mel of the four channels into out
+ * channels 0..3 and the three mel-projected intensity vectors (same definition as seld_foa_intensity) into channels 4..6 of
+ * out[n*sN + c*sC + m*sM + t*sT]; the spectra stay in LDS.  Extends dataset.py:27-58. */
+int seld_logmel_iv_f32(const float* pcm, int64_t N, int64_t L, float* out, int64_t sN, int64_t sC, int64_t sM, int64_t sT,
+                       void* stream);
+int seld_logmel_iv_i16(const int16_t* pcm, int64_t N, int64_t L, float* out, int64_t sN, int64_t sC, int64_t sM, int64_t sT,
+                       void* stream);
+
 /* GCC-PHAT of all C(C-1)/2 channel pairs (m < n, lexicographic) from spectra [N][C][F][481], 2 <= C <= 8:
  *   cc = irfft(R/|R|, 960) with R = conj(X_m) X_n (factor 1 where either channel's bin is silent, |X|^2 <= 1e-12);
  *   out[n*sN + pair*sC + j*sM + t*sT] = cc[(j - 32) mod 960], j = 0..63 (lags -32..31).  With sM == 1 and 16-byte

@@ -276,6 +276,146 @@ __global__ __launch_bounds__(kEdgeWaves * 64, 2) void stft_kernel(LogmelArgs a) 
   }
 }
 
+// ---- Fused FOA feature pass (north-star additions A15: log-mel + intensity vectors, no spectra in HBM).
+// One 4-wavefront workgroup = the channels W, X, Y, Z of one clip; it walks a contiguous run of that clip's iterations
+// (edge iterations included: the generic load path, chosen by a workgroup-uniform branch).  Per iteration: stages A-C per
+// channel as in the log-mel kernel -> W publishes its spectrum -> barrier -> X / Y / Z form the intensities of their bins
+// (logmel_core.h iv_compute) -> every channel's own log-mel bands -> barrier -> the intensities replace the power rows and go
+// through the same sparse mel pass.  LDS: tables 25.6 KB + 4 tiles 63.5 KB + W's spectrum 16 KB = 105 KB, one workgroup per
+// CU; the next iteration's samples are requested (clamped indices: never out of bounds, also past the run's end) before
+// the un-packing so that their latency is covered although a SIMD holds one wavefront.
+constexpr int kIvLdsBytes = (kTabFloats + kIvChannels * kLdsFloatsPerWave + kIvSpecFloats) * 4;
+constexpr float kIvEps = 1e-8f;
+
+template <typename T>
+__device__ __forceinline__ void iv_fetch(const LogmelArgs& a, long clip, long itr, int wave, int lane, float (&s)[48]) {
+  const T* row = static_cast<const T*>(a.pcm) + (clip * kIvChannels + wave) * a.L;
+  const long fa = itr * kFramesPerIter + 2 * (lane >> 5);
+  if (itr >= 1 && itr <= a.interior) load_samples<T, true>(lane, row, a.L, fa, s);
+  else load_samples<T, false>(lane, row, a.L, fa, s);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kIvChannels * 64, 1) void logmel_iv_kernel(LogmelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  float* tab = smem;
+  float* lds = smem + kTabFloats + wave * kLdsFloatsPerWave;
+  float* wspec = smem + kTabFloats + kIvChannels * kLdsFloatsPerWave;
+  fill_tables(a, tab, tid, kIvChannels * 64);
+  for (int i = lane; i < kLdsFloatsPerWave; i += 64) lds[i] = 0.0f;
+  const int seg = a.tab.mel_pos[lane];
+  float* pp[16];
+  power_row_pointers(lane, lds, a.tab.mel_pos, pp);
+  __syncthreads();
+  LaneConsts consts;
+  load_lane_consts(lane, tab, consts);
+
+  const long total = (a.rows / kIvChannels) * a.iters_per_row;       // (clip, iteration) pairs
+  const long begin = static_cast<long>(blockIdx.x) * a.chunk;
+  const long end = begin + a.chunk < total ? begin + a.chunk : total;
+  if (begin >= end) return;                                           // workgroup-uniform
+  long clip = begin / a.iters_per_row;
+  long itr = begin - clip * a.iters_per_row;
+  float s[48];
+  iv_fetch<T>(a, clip, itr, wave, lane, s);
+
+#pragma unroll 1
+  for (long it = begin; it < end; ++it) {
+    long nclip = clip, nitr = itr;
+    if (it + 1 < end) {
+      if (++nitr == a.iters_per_row) { nitr = 0; ++nclip; }
+    }
+    const long tf = itr * kFramesPerIter;
+    phase_a(lane, s, consts, lds);
+    SELD_WAVE_SYNC();
+    cf z[kN2];
+    phase_b(lane, lds, z);
+    SELD_WAVE_SYNC();
+    phase_b_store(lane, lds, z);
+    SELD_WAVE_SYNC();
+    iv_fetch<T>(a, nclip, nitr, wave, lane, s);                       // the next iteration's samples (this one's again at the end)
+    cf m[16];
+    phase_c_load(lane, lds, m);
+    cf xa[16], xb[16];
+    phase_c_unpack(lane, pp, z, m, xa, xb);
+    if (wave == 0) iv_publish(lane, wspec, xa, xb);
+    __syncthreads();
+    float ia[16], ib[16];
+    if (wave != 0) iv_compute(lane, wave, wspec, pp, xa, xb, kIvEps, ia, ib);
+    float* outp = a.out + clip * a.sN + lane * a.sM + tf * a.sT;
+    {
+      LaneAcc acc;
+      phase_d_accumulate(lane, lds, tab, seg, acc);
+      float below[kFramesPerIter], db[kFramesPerIter];
+#pragma unroll
+      for (int f = 0; f < kFramesPerIter; ++f) below[f] = lane_below(acc.ab[f].y);
+      phase_d_finish(acc, below, db);
+#pragma unroll
+      for (int f = 0; f < kFramesPerIter; ++f)
+        if (tf + f < a.F) outp[wave * a.sC + f * a.sT] = db[f];
+    }
+    __syncthreads();                                                  // every channel is done with every power row
+    if (wave != 0) {
+      iv_store_rows(lane, pp, ia, ib);
+      SELD_WAVE_SYNC();
+      LaneAcc acc;
+      phase_d_accumulate(lane, lds, tab, seg, acc);
+#pragma unroll
+      for (int f = 0; f < kFramesPerIter; ++f) {
+        const float v = acc.ab[f].x + lane_below(acc.ab[f].y);
+        if (tf + f < a.F) outp[(kIvChannels - 1 + wave) * a.sC + f * a.sT] = v;
+      }
+    }
+    SELD_WAVE_SYNC();
+    clip = nclip;
+    itr = nitr;
+  }
+}
+
+template <typename T>
+static int launch_logmel_iv(const T* pcm, int64_t N, int64_t L, float* out, const int64_t* strides, hipStream_t stream) {
+  DeviceState* st = current_state();
+  if (!st) return kErrNotInitialised;
+  if (!pcm || !out) return fail(kErrInvalidArgument, "seld_logmel_iv: null pointer");
+  if (N <= 0) return fail(kErrInvalidArgument, "seld_logmel_iv: N must be positive");
+  if (L <= kNfft / 2) return fail(kErrInvalidArgument, "seld_logmel_iv: reflect padding needs L > n_fft/2 = 480 samples");
+  if (L >= (1L << 30)) return fail(kErrUnsupported, "seld_logmel_iv: at most 2^30 samples per channel");
+  LogmelArgs a;
+  a.pcm = pcm;
+  a.out = out;
+  a.rows = N * kIvChannels;
+  a.C = kIvChannels;
+  a.L = L;
+  a.F = 1 + L / kHop;
+  a.iters_per_row = (a.F + kFramesPerIter - 1) / kFramesPerIter;
+  a.interior = (L / kHop - kFramesPerIter) / kFramesPerIter;          // as launch_logmel
+  if (a.interior < 0) a.interior = 0;
+  if (a.interior > a.iters_per_row - 1) a.interior = a.iters_per_row - 1;
+  a.edge_per_row = a.iters_per_row - a.interior;
+  a.sN = strides[0];
+  a.sC = strides[1];
+  a.sM = strides[2];
+  a.sT = strides[3];
+  a.tab = st->tables();
+  a.spec = nullptr;
+  a.main_blocks = 0;
+  const long total = N * a.iters_per_row;
+  long groups = total < st->num_cus ? total : static_cast<long>(st->num_cus);
+  a.chunk = (total + groups - 1) / groups;
+  groups = (total + a.chunk - 1) / a.chunk;
+  const unsigned bit = sizeof(T) == 4 ? kAttrLogmelIvF32 : kAttrLogmelIvI16;
+  if (need_lds(st, bit)) {                 // once per device (seld_common.h)
+    SELD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_iv_kernel<T>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kIvLdsBytes));
+    lds_attr_set(st, bit);
+  }
+  hipLaunchKernelGGL(logmel_iv_kernel<T>, dim3(static_cast<unsigned>(groups)), dim3(kIvChannels * 64), kIvLdsBytes, stream, a);
+  SELD_HIP_TRY(hipGetLastError());
+  return kOk;
+}
+
 template <typename T>
 static int launch_stft(const T* pcm, int64_t N, int64_t C, int64_t L, float* out, hipStream_t stream) {
   DeviceState* st = current_state();
@@ -448,6 +588,18 @@ int seld_logmel_phasors_i16(const int16_t* pcm, int64_t N, int64_t C, int64_t L,
   const int64_t strides[4] = {sN, sC, sM, sT};
   return seld::launch_logmel<int16_t, 2>(pcm, N, C, L, out, 0, static_cast<hipStream_t>(stream), strides,
                                          reinterpret_cast<float*>(phasors_q15));
+}
+
+int seld_logmel_iv_f32(const float* pcm, int64_t N, int64_t L, float* out, int64_t sN, int64_t sC, int64_t sM, int64_t sT,
+                       void* stream) {
+  const int64_t strides[4] = {sN, sC, sM, sT};
+  return seld::launch_logmel_iv<float>(pcm, N, L, out, strides, static_cast<hipStream_t>(stream));
+}
+
+int seld_logmel_iv_i16(const int16_t* pcm, int64_t N, int64_t L, float* out, int64_t sN, int64_t sC, int64_t sM, int64_t sT,
+                       void* stream) {
+  const int64_t strides[4] = {sN, sC, sM, sT};
+  return seld::launch_logmel_iv<int16_t>(pcm, N, L, out, strides, static_cast<hipStream_t>(stream));
 }
 
 int64_t seld_phasor_pitch(void) { return seld::kPhasorPitch; }

@@ -321,6 +321,80 @@ SELD_HD void phase_c_spectrum(int lane, const cf (&z)[kN2], const cf (&m)[16], f
   }
 }
 
+// ---- Fused FOA intensity vectors (logmel_iv_kernel, logmel.hip): the four wavefronts of a workgroup are the channels
+// W, X, Y, Z of the SAME four frames, in lock-step.  Every wavefront leaves its |C|^2 rows in its own tile (all four use one
+// mel_pos layout, so a lane finds the other channels' powers of ITS bins at its own offsets, one tile pitch apart), W also
+// publishes its un-packed complex spectrum lane-major in a workgroup buffer, and X / Y / Z form
+//     I_c[k] = Re(conj(W[k]) C[k]) / (eps + |W|^2 + (|X|^2 + |Y|^2 + |Z|^2) / 3)
+// for their 16 bins x 2 frames in registers; once every wavefront is done with the power rows the I values take their place
+// and the SAME sparse mel pass (phase_d_accumulate) projects them.  No spectrum ever goes to global memory.
+constexpr int kIvChannels = 4;
+constexpr int kIvSpecFloats = 16 * 2 * 64 * 2;          // W's spectrum: [r][frame a / b][lane] complex, 16 KB
+
+// Phase C keeping the un-packed spectra of this lane's bins l + 32 r:  Xa = (zr + mr, zi - mi),  Xb = (zi + mi, mr - zr)
+// (the 1/2 is in the window table); power rows exactly as phase_c_store writes them.
+SELD_HD void phase_c_unpack(int lane, float* const (&pp)[16], const cf (&z)[kN2], const cf (&m)[16], cf (&xa)[16],
+                            cf (&xb)[16]) {
+  const int l = lane & 31;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const cf u = cf_fma(cf_make(m[r].x, m[r].x), cf_make(1.0f, -1.0f), cf_make(z[r].x, z[r].x));   // (zr + mr, zr - mr)
+    const cf v = cf_fma(cf_make(m[r].y, m[r].y), cf_make(-1.0f, 1.0f), cf_make(z[r].y, z[r].y));   // (zi - mi, zi + mi)
+    const cf p = cf_fma(v, v, cf_mul(u, u));
+    xa[r] = cf_make(u.x, v.x);
+    xb[r] = cf_make(v.y, -u.y);
+    if (r < 15 || l == 0) {
+      pp[r][0] = p.x;
+      pp[r][kPPitch] = p.y;
+    }
+  }
+}
+
+// W's wavefront: spectrum of (r, frame) at complex index (2 r + frame) * 64 + lane -- linear 8-byte stores / loads
+SELD_HD void iv_publish(int lane, float* wspec, const cf (&xa)[16], const cf (&xb)[16]) {
+  cf* w = reinterpret_cast<cf*>(wspec) + lane;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    w[(2 * r) * 64] = xa[r];
+    w[(2 * r + 1) * 64] = xb[r];
+  }
+}
+
+// Channel `chan` (1..3): the intensities of this lane's bins.  ``pp`` are the lane's OWN power-row pointers; channel k's
+// tile is (k - chan) * kLdsFloatsPerWave floats away.
+SELD_HD void iv_compute(int lane, int chan, const float* wspec, float* const (&pp)[16], const cf (&xa)[16],
+                        const cf (&xb)[16], float eps, float (&ia)[16], float (&ib)[16]) {
+  const int l = lane & 31;
+  const cf* w = reinterpret_cast<const cf*>(wspec) + lane;
+  const int t0 = -chan * kLdsFloatsPerWave;              // W's tile relative to this channel's
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    ia[r] = 0.0f;
+    ib[r] = 0.0f;
+    if (r < 15 || l == 0) {
+      const float* q = pp[r] + t0;
+      const float ea = eps + q[0] + ((q[kLdsFloatsPerWave] + q[2 * kLdsFloatsPerWave]) + q[3 * kLdsFloatsPerWave]) * (1.0f / 3.0f);
+      const float eb = eps + q[kPPitch] + ((q[kLdsFloatsPerWave + kPPitch] + q[2 * kLdsFloatsPerWave + kPPitch]) +
+                                           q[3 * kLdsFloatsPerWave + kPPitch]) * (1.0f / 3.0f);
+      const cf wa = w[(2 * r) * 64], wb = w[(2 * r + 1) * 64];
+      ia[r] = (wa.x * xa[r].x + wa.y * xa[r].y) * (1.0f / ea);          // Re(conj(W) C) = wr cr + wi ci
+      ib[r] = (wb.x * xb[r].x + wb.y * xb[r].y) * (1.0f / eb);
+    }
+  }
+}
+
+// the intensities take the place of the power rows (same cells: the mel pass reads them with the same segment layout)
+SELD_HD void iv_store_rows(int lane, float* const (&pp)[16], const float (&ia)[16], const float (&ib)[16]) {
+  const int l = lane & 31;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (r < 15 || l == 0) {
+      pp[r][0] = ia[r];
+      pp[r][kPPitch] = ib[r];
+    }
+  }
+}
+
 // ---- Phase D: sparse mel.  Lane j accumulates over its own contiguous bins for all 4 frames.
 // The filter weights come from the workgroup's LDS table (12 linear ds_read_b128 per iteration).
 SELD_HD void phase_d_accumulate(int lane, float* lds, const float* tab, int seg, LaneAcc& acc) {

@@ -64,6 +64,8 @@ enum LdsAttrBit : unsigned {
   kAttrLogmelPhasorF32 = 1u << 10,
   kAttrLogmelPhasorI16 = 1u << 11,
   kAttrGccMfmaQ15 = 1u << 12,
+  kAttrLogmelIvF32 = 1u << 13,
+  kAttrLogmelIvI16 = 1u << 14,
 };
 
 // true when `bit` still has to be set up on this device (the caller then sets its attributes and calls lds_attr_set)

@@ -54,6 +54,8 @@ def _declare(lib):
     for name in ("seld_stft_f32", "seld_stft_i16"):
         getattr(lib, name).argtypes = [_ptr, _i64, _i64, _i64, _ptr, _ptr]
     lib.seld_foa_intensity.argtypes = [_ptr, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr]
+    for fn in (lib.seld_logmel_iv_f32, lib.seld_logmel_iv_i16):
+        fn.argtypes = [_ptr, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr]
     for fn in (lib.seld_logmel_spectrum_f32, lib.seld_logmel_spectrum_i16):
         fn.argtypes = [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr]
         fn.restype = ctypes.c_int
@@ -1063,6 +1065,13 @@ def spatial_features(pcm: torch.Tensor, kind: str) -> torch.Tensor:
             check(fn(_p(pcm), n, c, length, _p(out), s_n, s_c, s_m, s_t, _p(phasors), stream), "seld_logmel_phasors")
             tail = ctypes.c_void_p(out.data_ptr() + c * N_MELS * 4)          # channel offset c
             check(lib.seld_gcc_phat_q15(_p(phasors), n, c, frames, tail, s_n, s_c, s_m, s_t, stream), "seld_gcc_phat_q15")
+        return out[0] if squeeze else out
+    if kind == "logmel_iv" and os.environ.get("SELD_FOA", "fused") != "spectra":
+        # default: ONE kernel -- the four channels of a clip meet in one workgroup, the spectra stay in LDS
+        # (csrc/logmel.hip logmel_iv_kernel; SELD_FOA=spectra: the two-kernel form through complex64 spectra, developer A/B)
+        fn = lib.seld_logmel_iv_f32 if pcm.dtype == torch.float32 else lib.seld_logmel_iv_i16
+        with _device_guard(index):
+            check(fn(_p(pcm), n, length, _p(out), s_n, s_c, s_m, s_t, stream), "seld_logmel_iv")
         return out[0] if squeeze else out
     with _device_guard(index):
         # one pass over the PCM: the log-mel channels and the spectra the spatial kernels read

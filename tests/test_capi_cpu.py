@@ -130,6 +130,31 @@ def test_lane_emulator_layouts_int16_and_floor(emu_lib):
     assert (_emu(emu_lib, torch.zeros(1, 5000)) == -100.0).all()
 
 
+@pytest.mark.parametrize("num_samples,seed", [(481, 5), (960, 5), (7681, 5), (24123, 6)])
+def test_lane_emulator_fused_foa_pass_matches_oracle(emu_lib, num_samples, seed):
+    """The fused FOA kernel's per-lane functions (csrc/logmel_core.h: phase_c_unpack, iv_publish, iv_compute, iv_store_rows)
+    stepped on the CPU as four lock-step wavefronts with the kernel's LDS layout (four contiguous tiles + W's spectrum
+    buffer, guard cells around them): log-mel channels as the plain emulation, intensity vectors against the float64 oracle
+    to the 1e-4 of the GPU test -- edge iterations (reflection, frames past the end) included."""
+    pcm = ofeat.synth_pcm(seed, 4, num_samples, "noise")
+    pcm[1] = 0.7 * pcm[0] + 0.3 * pcm[1]
+    pcm[:, num_samples // 2: num_samples // 2 + 100] = 0.0                 # a stretch of digital silence: eps carries it
+    frames = 1 + num_samples // 480
+    batch = torch.stack([pcm, ofeat.synth_pcm(seed + 10, 4, num_samples, "noise")])
+    x = np.ascontiguousarray(batch.numpy())
+    out = np.full((2, frames, 7, 64), np.nan, np.float32)
+    fb = np.ascontiguousarray(ofeat.mel_filterbank_htk().numpy())
+    rc = emu_lib.emu_logmel_iv_f32(ctypes.c_void_p(x.ctypes.data), ctypes.c_int64(2), ctypes.c_int64(num_samples),
+                                   ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(fb.ctypes.data))
+    assert rc == 0                                                         # (-9: an LDS index left the block)
+    assert np.isfinite(out).all()
+    for i in range(2):
+        assert np.array_equal(out[i, :, :4].transpose(1, 2, 0), _emu(emu_lib, batch[i]))
+        ref = ofeat.foa_intensity_f64(batch[i].numpy())                    # [3, 64, F]
+        assert np.abs(out[i, :, 4:].transpose(1, 2, 0) - ref).max() <= 1e-4
+    assert np.abs(ofeat.foa_intensity_f64(pcm.numpy())[0]).max() > 0.1
+
+
 def test_device_code_has_no_vcc_scc_select_miscompile(tmp_path):
     """hipcc (ROCm 7.2, gfx950) lowered a uniform 64-bit ``min(n - cell0, 256)`` in two instantiations of the loss
     kernel to ``v_cmp_lt_i64 vcc`` + ``s_cselect_b32`` WITHOUT copying VCC to SCC: the select then read the stale

@@ -28,8 +28,12 @@ def test_stft_matches_torch_stft(gpu_device, num_samples):
     assert_logmel_close(seld_native.logmel(pcm.to(gpu_device)).cpu().numpy(), db.numpy())
 
 
-def test_foa_intensity_vectors(gpu_device):
+@pytest.mark.parametrize("path", ["fused", "spectra"])
+def test_foa_intensity_vectors(gpu_device, path, monkeypatch):
+    """Both FOA paths: the one-kernel pass (default: the four channels of a clip in one workgroup, spectra in LDS only) and
+    the two-kernel form through complex64 spectra in HBM (SELD_FOA=spectra)."""
     import seld_native
+    monkeypatch.setenv("SELD_FOA", path)
     pcm = ofeat.synth_pcm(4, 4, 24000, "noise")
     pcm[1] = 0.7 * pcm[0] + 0.3 * pcm[1]                                  # correlate X with W: non-trivial vectors
     feat = seld_native.spatial_features(pcm.to(gpu_device), "logmel_iv").cpu()      # [F, 7, 64]
@@ -120,17 +124,27 @@ def test_gcc_phat_full_size_clip_and_kernel_variants(gpu_device, monkeypatch):
         assert np.abs(got - ref[:, :, 2:99]).max() <= 1e-4
 
 
-def test_foa_intensity_full_size_clip(gpu_device):
-    """The FOA feature set at workload size: a 60 s 4-channel clip (3001 frames) through seld_foa_intensity -- excerpts
-    spread over the clip agree with the float64 oracle computed on their own samples (interior frames), the log-mel
-    channels of the same pass equal the plain log-mel call bit for bit, a planted W-X correlation shows in channel 0."""
+@pytest.mark.parametrize("path", ["fused", "spectra"])
+def test_foa_intensity_full_size_clip(gpu_device, path, monkeypatch):
+    """The FOA feature set at workload size: a 60 s 4-channel clip (3001 frames) through both FOA paths -- excerpts
+    spread over the clip agree with the float64 oracle computed on their own samples (interior frames), a planted W-X
+    correlation shows in channel 0, and the log-mel channels of the same pass equal the plain log-mel call: bit for bit in
+    the two-kernel form (the same kernel template), to the log-mel bar in the one-kernel form (another function body: the
+    compiler fuses the transforms' multiply-adds differently -- last-bit differences, printed)."""
     import seld_native
+    monkeypatch.setenv("SELD_FOA", path)
     pcm = ofeat.synth_pcm(31, 4, 1_440_000, "noise")
     pcm[1] = 0.6 * pcm[0] + 0.4 * pcm[1]
     dev = pcm.to(gpu_device)
     feat = seld_native.spatial_features(dev, "logmel_iv")                 # [3001, 7, 64]
     assert tuple(feat.shape) == (3001, 7, 64)
-    assert torch.equal(feat[:, :4], seld_native.logmel(dev, layout="tcf"))
+    plain = seld_native.logmel(dev, layout="tcf")
+    if path == "spectra":
+        assert torch.equal(feat[:, :4], plain)
+    else:
+        print(f"fused FOA pass vs plain log-mel kernel: max |dB difference| = {(feat[:, :4] - plain).abs().max().item():.3e}, "
+              f"{(feat[:, :4] != plain).float().mean().item():.3%} of the values differ")
+        assert_logmel_close(feat[:, :4].permute(1, 2, 0).cpu().numpy(), plain.permute(1, 2, 0).cpu().numpy())
     iv = feat[:, 4:].cpu().numpy()                                        # [F, 3, 64]
     assert np.isfinite(iv).all() and np.abs(iv[:, 0]).mean() > 0.05
     for start in (0, 480 * 1458, 1_440_000 - 48_000):
