@@ -214,4 +214,7 @@ int emu_logmel_i16(const int16_t* pcm, int64_t N, int64_t C, int64_t L, float* o
 int emu_logmel_iv_f32(const float* pcm, int64_t N, int64_t L, float* out, const float* fb) {
   return run_iv<float>(pcm, N, L, out, fb);
 }
+int emu_logmel_iv_i16(const int16_t* pcm, int64_t N, int64_t L, float* out, const float* fb) {
+  return run_iv<int16_t>(pcm, N, L, out, fb);
+}
 }

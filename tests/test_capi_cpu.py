@@ -153,6 +153,15 @@ def test_lane_emulator_fused_foa_pass_matches_oracle(emu_lib, num_samples, seed)
         ref = ofeat.foa_intensity_f64(batch[i].numpy())                    # [3, 64, F]
         assert np.abs(out[i, :, 4:].transpose(1, 2, 0) - ref).max() <= 1e-4
     assert np.abs(ofeat.foa_intensity_f64(pcm.numpy())[0]).max() > 0.1
+    if num_samples == 7681:                                                # the int16 instantiation's sample conversion
+        xi = ofeat.pcm_to_int16(pcm)
+        x16 = np.ascontiguousarray(xi.numpy()[None])
+        out16 = np.full((1, frames, 7, 64), np.nan, np.float32)
+        rc = emu_lib.emu_logmel_iv_i16(ctypes.c_void_p(x16.ctypes.data), ctypes.c_int64(1), ctypes.c_int64(num_samples),
+                                       ctypes.c_void_p(out16.ctypes.data), ctypes.c_void_p(fb.ctypes.data))
+        assert rc == 0
+        ref16 = ofeat.foa_intensity_f64(ofeat.int16_to_pcm(xi).numpy())
+        assert np.abs(out16[0, :, 4:].transpose(1, 2, 0) - ref16).max() <= 1e-4
 
 
 def test_device_code_has_no_vcc_scc_select_miscompile(tmp_path):
