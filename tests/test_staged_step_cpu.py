@@ -123,3 +123,27 @@ def test_two_gloo_ranks_overlapped_exchange_equals_the_blocking_one():
         assert a[key][0] == base[0]
         assert a[key][0] != b[key][0]                                 # the ranks really saw different batches
     assert a[(True, "param")][2] is True and a[(True, "param")][3] == 3
+
+
+def test_four_gloo_ranks_stay_in_sync_under_the_overlapped_exchange():
+    """Four ranks: more than one hop in the collective.  Replicas agree bit for bit in every mode; staged and blocking
+    exchanges agree to rounding (their buffers are cut differently, so a ring may add the four contributions in another
+    order -- with two ranks the sum is commutative and the test above demands equality)."""
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 311
+    procs = [ctx.Process(target=_rank, args=(r, 4, port, queue)) for r in range(4)]
+    for p in procs:
+        p.start()
+    results = [out for _, out in sorted((queue.get(timeout=300) for _ in procs), key=lambda t: t[0])]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    base = results[0][(False, "param")]
+    for key in results[0]:
+        for other in results[1:]:
+            assert results[0][key][1] == other[key][1], key               # replicas agree
+        assert torch.allclose(torch.tensor(results[0][key][1]), torch.tensor(base[1]), rtol=1e-5, atol=1e-6), key
+        assert all(abs(x - y) <= 1e-5 * abs(y) for x, y in zip(results[0][key][0], base[0])), key
+    assert len({tuple(r[(True, "param")][0]) for r in results}) == 4      # four different batches
+    assert results[0][(True, "param")][2] is True and results[0][(True, "param")][3] == 3
