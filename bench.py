@@ -350,8 +350,8 @@ def kernel_rooflines(device):
         clips * (8 * CLIP_SAMPLES * 4 + 36 * 64 * (1 + CLIP_SAMPLES // 480) * 4),
         timeit(lambda: nat.spatial_features(pcm8, "logmel_gcc"), reps=3))
     del pcm8
-    # the FOA feature set: log-mel + spectra in one pass (logmel_main_kernel<float, 1>), then seld::foa_iv_kernel
-    # (mel-projected intensity vectors): 4 x 5.76 MB PCM in + 7 x 64 x 3001 x 4 B out per clip
+    # the FOA feature set: log-mel and the mel-projected intensity vectors in one kernel (seld::logmel_iv_kernel: the four
+    # channels of a clip in one workgroup, spectra in LDS only): 4 x 5.76 MB PCM in + 7 x 64 x 3001 x 4 B out per clip
     pcm4 = torch.randn(clips, 4, CLIP_SAMPLES, device=device) * 0.1
     hbm(f"spatial_features logmel_iv ({clips} clips x 4 ch FOA: logmel_iv_kernel<float>, one pass)",
         clips * (4 * CLIP_SAMPLES * 4 + 7 * 64 * (1 + CLIP_SAMPLES // 480) * 4),
