@@ -15,5 +15,5 @@ else
   bash tools/prof_bench.sh ${TAG}_resnet_conformer --model resnet_conformer --loss three_term --gaussian-augment --steps 2 > gpurun_out/prof_${TAG}_resnet_conformer.log 2>&1; cat gpurun_out/prof_${TAG}_resnet_conformer/timed_region.log
   bash tools/prof_bench.sh ${TAG}_mic8_gcc --features logmel_gcc --channels 8 > gpurun_out/prof_${TAG}_mic8_gcc.log 2>&1; cat gpurun_out/prof_${TAG}_mic8_gcc/timed_region.log
   PMC_KEEP_ROWS=24 bash tools/pmc_kernel.sh ${TAG}_spatial "gcc_q15|gcc_mfma|logmel_main" python3 $GRAFT_REPO_ROOT/tools/bench_spatial.py logmel_gcc 8 8 3 > gpurun_out/pmc_${TAG}_spatial.log 2>&1; tail -3 gpurun_out/pmc_${TAG}_spatial.log
-  PMC_KEEP_ROWS=24 bash tools/pmc_kernel.sh ${TAG}_foa "foa_iv|logmel_main" python3 $GRAFT_REPO_ROOT/tools/bench_spatial.py logmel_iv 4 8 3 > gpurun_out/pmc_${TAG}_foa.log 2>&1; tail -3 gpurun_out/pmc_${TAG}_foa.log
+  PMC_KEEP_ROWS=24 bash tools/pmc_kernel.sh ${TAG}_foa "logmel_iv|foa_iv|logmel_main" python3 $GRAFT_REPO_ROOT/tools/bench_spatial.py logmel_iv 4 8 3 > gpurun_out/pmc_${TAG}_foa.log 2>&1; tail -3 gpurun_out/pmc_${TAG}_foa.log
 fi
