@@ -80,6 +80,18 @@ def test_batched_spatial_features(gpu_device):
         assert torch.equal(gcc[i], seld_native.spatial_features(pcm[i], "logmel_gcc"))
 
 
+def test_fused_foa_pass_runs_that_cross_clip_boundaries(gpu_device):
+    """40 clips of 13 iterations = 520 (clip, iteration) pairs on 256 CUs: every workgroup of the one-kernel FOA pass walks
+    3 consecutive pairs, most of them across a clip boundary (last iteration of one clip, first -- reflected -- of the next).
+    Each clip alone is one pair per workgroup: the two must agree bit for bit."""
+    import seld_native
+    pcm = torch.stack([ofeat.synth_pcm(40 + i, 4, 24000, "noise") for i in range(40)]).to(gpu_device)
+    batched = seld_native.spatial_features(pcm, "logmel_iv")
+    assert tuple(batched.shape) == (40, 51, 7, 64) and torch.isfinite(batched).all()
+    for i in range(40):
+        assert torch.equal(batched[i], seld_native.spatial_features(pcm[i], "logmel_iv")), i
+
+
 @pytest.mark.parametrize("kernel", ["mfma", "planar", "spectra", "fft"])
 def test_gcc_phat_with_a_silent_channel(gpu_device, kernel, monkeypatch):
     """X = 0 must give R / |R| = 1 (np.exp(1j * np.angle(0))): pairs with the dead microphone are a unit pulse at lag 0,
