@@ -194,6 +194,44 @@ def test_device_code_has_no_vcc_scc_select_miscompile(tmp_path):
                 f"{src.name}: '{line.strip()}' selects on the SCC of '{writer}' after '{wide_cmp[0].strip()}'"
 
 
+def test_hot_kernels_do_not_spill():
+    """Register claims of DESIGN.md checked on the CPU: the compiler's own resource report (-Rpass-analysis=kernel-resource-usage)
+    of the feature and recurrence kernels must show NO scratch -- the round-2 review found 56 B per lane in
+    ``logmel_main_kernel<float, 1>`` by recompiling; a spill in one of these is a silent 10 - 30 % on a tuned kernel."""
+    import re
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    from pathlib import Path
+    csrc = Path(__file__).resolve().parent.parent / "sound-event-localization-detection_amd" / "csrc"
+    must_not_spill = {"logmel.hip": ("logmel_main_kernel", "logmel_iv_kernel", "stft_kernel"),
+                      "spatial.hip": ("gcc_q15_kernel", "gcc_mfma_kernel", "foa_iv_kernel"),
+                      # (the bf16 instantiations: what a training iteration runs; the fp32 build of the backward kernel, a
+                      #  test yardstick, carries 16 B)
+                      "gru.hip": ("gru_forward_kernelI14__hip_bfloat16", "gru_backward_kernelI14__hip_bfloat16")}
+
+    def report(name):
+        run = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950",
+                              f"-I{csrc.parent.parent / 'include'}", "-Rpass-analysis=kernel-resource-usage", "-c",
+                              str(csrc / name), "-o", "/dev/null"], capture_output=True, text=True)
+        assert run.returncode == 0, run.stderr[-2000:]
+        found, current = {}, None
+        for line in run.stderr.splitlines():
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                current = m.group(1)
+            m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+            if m and current:
+                found[current] = int(m.group(1))
+        return name, found
+
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        for name, found in pool.map(report, must_not_spill):
+            for kernel in must_not_spill[name]:
+                hits = {k: v for k, v in found.items() if kernel in k}
+                assert hits, (name, kernel, sorted(found))
+                assert all(v == 0 for v in hits.values()), (name, hits)
+
+
 def test_gcc_table_reproduces_irfft_lags():
     """The constant operand of the matrix-core GCC-PHAT kernel (csrc/spatial.hip, seld_gcc_table_host: fp16 cosine / sine
     fragments) and the way the kernel combines its two products -- cc[+l] = (C[l] + S[l]) / 960, cc[-l] = (C[l] - S[l]) /
